@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- stacked Mpixels/s of the per-pixel stacking hot path on MI355X.
+
+One "step" = one full stack pass (OpStack.Apply's numeric core,
+internal/ops/stack/stack.go:142-218) over a synthetic sub-exposure stack that
+is already resident in HBM.  Default workload = BASELINE.json configs[1]:
+128 x 4096 x 4096 fp32 frames, sigma-clipped mean, kappa = 3, one GPU.
+
+With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank
+owns one row tile of the same size (weak scaling: the image grows with N); the
+only exchange is the all-reduce of the two clip counters per pass (RCCL).
+
+Prints ONE JSON line on rank 0 (contract in the task description) including
+  roofline     algorithmic HBM bytes (4*P*(N+1)) / HIP-event kernel time
+  cpu_baseline the CPU oracle (C restatement of the Go reference) timed on a
+               bounded strip of the same stack with all host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+MODE_NAMES = {0: "median", 1: "mean", 2: "sigma-clip", 3: "winsorized sigma-clip",
+              4: "MAD sigma-clip", 5: "linear-fit"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=128)
+    ap.add_argument("--width", type=int, default=4096)
+    ap.add_argument("--height", type=int, default=4096, help="rows per GPU")
+    ap.add_argument("--mode", type=int, default=2)
+    ap.add_argument("--kappa", type=float, default=3.0)
+    ap.add_argument("--cpu-rows", type=int, default=0,
+                    help="rows of the stack timed on the CPU (0 = auto, about 10-30 s)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(st, args, rows):
+    """Times the oracle (oracle/nl_oracle.c, a C restatement of the Go reference:
+    same batching rule, one worker per host core) on the first `rows` rows."""
+    import numpy as np
+    from oracle import oracle
+    n, w = args.frames, args.width
+    frames = np.empty((n, rows * w), np.float32)
+    for i in range(n):
+        frames[i] = st.download_tile(i)[: rows * w]
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    rc, res, cl, ch, _ = oracle.stack_apply(args.mode, frames, None, args.kappa, args.kappa,
+                                            0.0, num_cpu=cores)
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    return {"value": round(rows * w / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores,
+            "kind": "port",
+            "sample": "first %d rows x %d px x %d frames of the same synthetic stack, %s, "
+                      "C restatement of the Go reference (no Go toolchain), %.1f s"
+                      % (rows, w, n, MODE_NAMES[args.mode], dt)}, res, (cl, ch)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    from nightlight_amd import StackHandle
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    n, w, rows = args.frames, args.width, args.height
+    total_rows = rows * world
+    st = StackHandle(n, w, total_rows, row0=rank * rows, rows=rows, device=local_rank)
+    st.fill_synthetic()
+    counters = torch.zeros(2, dtype=torch.int64, device="cuda")
+
+    def step():
+        st.run_async(args.mode, args.kappa, args.kappa, 0.0)
+        cl, ch = st.finish()
+        if dist is not None:     # global clip totals, as the log line of stack.go:214-218 needs
+            counters[0], counters[1] = cl, ch
+            dist.all_reduce(counters)
+        return cl, ch
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cl, ch = step()
+        kernel_ms.append(st.last_kernel_ms)
+    fence()
+    dt = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        pixels_per_step = rows * w * world
+        ms_per_step = dt * 1e3 / args.steps
+        value = pixels_per_step * args.steps / dt / 1e6
+        k_ms = float(np.mean(kernel_ms))
+        alg_bytes = 4.0 * rows * w * (n + 1)          # per launch (one tile), SURVEY 8d
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "stacked Mpixels/sec (%s, %dx%dx%d fp32)" % (MODE_NAMES[args.mode], n, rows, w),
+            "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d x %dx%d fp32 frames per GPU, %s kappa=%g, frames resident in HBM"
+                                   % (n, rows, w, MODE_NAMES[args.mode], args.kappa),
+                       "frames": n, "width": w, "rows_per_gpu": rows, "mode": args.mode,
+                       "sharding": "row tiles, %d rank(s); all-reduce of 2 int64 clip counters per pass" % world,
+                       "clip_low": int(counters[0].item()) if dist is not None else cl,
+                       "clip_high": int(counters[1].item()) if dist is not None else ch},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": None, "kernel": st.last_kernel_name,
+                         "kernel_ms": round(k_ms, 4), "algorithmic_bytes": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu:
+            cpu_rows = args.cpu_rows
+            if cpu_rows <= 0:   # about 10-30 s of CPU work on a small host
+                cpu_rows = max(8, min(rows, int(4.0e9 / (n * w) / 8)))
+            cpu_rows = min(cpu_rows, rows)
+            base, res, cc = cpu_baseline(st, args, cpu_rows)
+            # parity in the same run: GPU strip vs oracle strip
+            got = st.result_tile()[: cpu_rows * w]
+            same = bool(np.array_equal(got, res, equal_nan=True))
+            base["parity_with_gpu"] = "bit-exact" if same else "MISMATCH"
+            out["cpu_baseline"] = base
+        print(json.dumps(out), flush=True)
+
+    st.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+/*
+ * nlstack.h -- C ABI of libnlstack.so: MI355X (gfx950) implementation of
+ * Nightlight's per-pixel stacking hot path.
+ *
+ * This is the drop-in boundary.  A thin cgo shim (go/ and INTEGRATION.md)
+ * binds exactly these entry points from a replacement of the reference's
+ * `internal/ops/stack` package, keeping the ops.Operator surface
+ * (internal/ops/operator.go:135-138) and OpStack's JSON fields
+ * (internal/ops/stack/stack.go:66-73) unchanged.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is caller-owned and is NOT retained
+ *     after the call returns (cgo pointer rules), except device pointers the
+ *     caller explicitly lends with nl_stack_attach_device_frames();
+ *   - functions returning int return NL_OK (0) or a negative NL_ERR_* code and
+ *     never abort; nl_last_error() gives the message of the calling thread's
+ *     last failure (the Go shim turns it into an `error`);
+ *   - every entry point selects its handle's device itself (goroutines migrate
+ *     between OS threads; SURVEY.md section 8b "Threading");
+ *   - stack modes are numbered exactly as StackMode, stack.go:33-42.
+ *
+ * Data layout in HBM: frames are planar [n_frames][rows*width] fp32 for the
+ * row tile [row0, row0+rows) of a width x height image (whole image: row0=0,
+ * rows=height).  NaN = "no data" (alignment out-of-bounds), as the reference.
+ */
+#ifndef NLSTACK_H
+#define NLSTACK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* StackMode, internal/ops/stack/stack.go:33-42 */
+#define NL_ST_MEDIAN        0
+#define NL_ST_MEAN          1
+#define NL_ST_SIGMA         2
+#define NL_ST_WINSOR_SIGMA  3
+#define NL_ST_MAD_SIGMA     4
+#define NL_ST_LINEAR_FIT    5
+#define NL_ST_AUTO          6
+
+/* StackWeighting, internal/ops/stack/stack.go:57-63 */
+#define NL_WEIGHT_NONE           0
+#define NL_WEIGHT_EXPOSURE       1
+#define NL_WEIGHT_INVERSE_NOISE  2
+#define NL_WEIGHT_INVERSE_HFR    3
+
+#define NL_OK                      0
+#define NL_ERR_INVALID_MODE       -1  /* "invalid stacking mode", stack.go:119 */
+#define NL_ERR_MISSING_EXPOSURE   -2  /* "%d: Missing exposure information ...", stack.go:238 */
+#define NL_ERR_INVALID_WEIGHTING  -3  /* "Invalid weighting mode %d", stack.go:267 */
+#define NL_ERR_WEIGHTED_MAD       -4  /* the reference panics (stack.go:185); we return an error */
+#define NL_ERR_NO_INPUTS          -5  /* "stack operator needs inputs", stack.go:103 */
+#define NL_ERR_INVALID_ARG        -6
+#define NL_ERR_HIP                -7  /* HIP runtime failure; message has the hipError string */
+#define NL_ERR_TOO_MANY_FRAMES    -8  /* per-pixel column does not fit the 160 KiB LDS */
+#define NL_ERR_NO_DEVICE          -9
+
+typedef struct nl_stack nl_stack_t;
+
+/* message of the calling thread's last error ("" if none) */
+const char *nl_last_error(void);
+/* number of visible HIP devices, or a negative error */
+int nl_device_count(void);
+/* library version string */
+const char *nl_version(void);
+
+/* ---- handle: replaces the per-call state of OpStack.Apply (stack.go:115-227) ---- */
+
+/* Allocates the planar [n_frames][rows*width] device buffer, the result tile
+ * and the counter scratch on `device`.  Returns NULL on failure. */
+nl_stack_t *nl_stack_create(int n_frames, int width, int height, int row0, int rows, int device);
+void nl_stack_destroy(nl_stack_t *h);
+
+/* Copies the handle's row tile out of one full host frame (width*height
+ * floats = fits.Image.Data, internal/fits/fits.go:42) into slot `idx`.
+ * Synchronous; the pointer is not retained.  One call per Go slice. */
+int nl_stack_upload_frame(nl_stack_t *h, int idx, const float *host_frame);
+/* Same, but the host buffer holds only the tile (rows*width floats). */
+int nl_stack_upload_tile(nl_stack_t *h, int idx, const float *host_tile);
+/* Device address of the planar frame buffer (for in-place producers that
+ * already live on the GPU); valid until destroy/attach. */
+void *nl_stack_frames_device_ptr(nl_stack_t *h);
+/* Lends an existing device buffer of the same layout instead of the owned
+ * one (NULL restores the owned buffer).  The caller keeps it alive. */
+int nl_stack_attach_device_frames(nl_stack_t *h, void *device_frames);
+/* Fills all frames on the device with the deterministic synthetic stack of
+ * SURVEY.md section 8d (sky gradient + per-frame gain/offset/noise, 0.4 % hot
+ * and 0.1 % cold outliers, NaN borders, one all-NaN 8x8 patch).  Pixel
+ * coordinates are those of the full image, so tiles agree with the whole. */
+int nl_stack_fill_synthetic(nl_stack_t *h, uint64_t seed);
+/* Downloads frame `idx`'s tile (rows*width floats). */
+int nl_stack_download_tile(nl_stack_t *h, int idx, float *host_tile);
+
+/* getWeights (stack.go:231-270).  weights: n_frames floats or NULL = none. */
+int nl_stack_set_weights(nl_stack_t *h, const float *weights);
+/* Computes the weights from per-frame scalars exactly as getWeights does:
+ * NL_WEIGHT_EXPOSURE: w=exposure (error if 0, *bad_index = frame);
+ * NL_WEIGHT_INVERSE_NOISE / _HFR: w = 1/(1+4*(v-min)/(max-min)).
+ * Pure host arithmetic, no device work. */
+int nl_weights_from_scalars(int weighting, const float *per_frame, int n_frames,
+                            float *weights_out, int *bad_index);
+
+/* One stack pass = the numeric core of OpStack.Apply (stack.go:142-218):
+ * runs Stack{Median,Mean,MeanWeighted,Sigma,SigmaWeighted,MADSigma,
+ * WinsorSigma,WinsorSigmaWeighted,LinearFit} (stack.go:274-918) over the tile.
+ * mode NL_ST_AUTO is resolved from n_frames as stack.go:45-55.
+ * out_host: full-image buffer (width*height floats); the tile's rows are
+ * written at offset row0*width.  NULL leaves the result on the device.
+ * clip_low/high: totals for THIS tile (sum them across tiles/ranks). */
+int nl_stack_run(nl_stack_t *h, int mode, float sigma_low, float sigma_high, float ref_loc,
+                 float *out_host, int64_t *clip_low, int64_t *clip_high);
+/* Asynchronous split of the same: enqueue on the handle's stream ... */
+int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_high, float ref_loc);
+/* ... then wait and fetch.  Any of the three outputs may be NULL. */
+int nl_stack_finish(nl_stack_t *h, float *out_host, int64_t *clip_low, int64_t *clip_high);
+/* Device address of the result tile (rows*width floats). */
+void *nl_stack_result_device_ptr(nl_stack_t *h);
+/* Mode actually run by the last pass (after NL_ST_AUTO resolution). */
+int nl_stack_last_mode(nl_stack_t *h);
+/* GPU time of the last pass's kernels in ms, from HIP events recorded on the
+ * handle's stream around the launches (valid after finish/run). */
+float nl_stack_last_kernel_ms(nl_stack_t *h);
+/* Name of the dominant kernel launched by the last pass (for profiles). */
+const char *nl_stack_last_kernel_name(nl_stack_t *h);
+
+/* ---- goal-seek (spec: internal/ops/stack/stackfindsigma.go:48-98) ----
+ * Bisection on sigma_low / sigma_high in [1,11] until the clipped
+ * percentages match the targets to 0.01 % or 21 passes were made.  After each
+ * pass the tile's {clip_low, clip_high} are handed to `reduce` (may be NULL
+ * for a single tile) which must replace them with the totals over all tiles
+ * -- e.g. an RCCL all-reduce -- so every rank takes the same branch.
+ * total_samples = width*height*n_frames of the WHOLE image. */
+typedef int (*nl_reduce_fn)(int64_t *counters2, void *user);
+int nl_stack_find_sigmas(nl_stack_t *h, int mode, float ref_loc,
+                         float clip_perc_low, float clip_perc_high,
+                         nl_reduce_fn reduce, void *user,
+                         float *out_host, int64_t *clip_low, int64_t *clip_high,
+                         float *sigma_low, float *sigma_high, int *passes);
+
+/* ---- stack of stacks (StackIncremental / Finalize, stack.go:924-944) ----
+ * acc += result_of_last_pass * weight (first != 0: acc = result*weight),
+ * on the device; finalize multiplies by 1/weight_sum and downloads. */
+int nl_stack_accumulate(nl_stack_t *h, float weight, int first);
+int nl_stack_accumulate_finalize(nl_stack_t *h, float weight_sum, float *out_host);
+
+/* ---- per-frame statistics on resident frames (internal/stats) ----
+ * calcMinMeanMax + calcVariance (stats_amd64.s:28-143, stats.go:264-287):
+ * min/max fp32, mean with fp64 accumulation, variance = sum((x-mean)^2)/n in
+ * fp64.  NaN-free input is assumed, as in the reference. */
+int nl_stack_frame_stats(nl_stack_t *h, int idx, float *mn, float *mean, float *mx,
+                         double *variance);
+/* EstimateNoise (stats/noise.go:32-55, noise_amd64.s:78-195).  Needs a
+ * whole-image handle (row0=0, rows=height). */
+int nl_stack_frame_noise(nl_stack_t *h, int idx, float *noise);
+/* Noise of every frame -> inverse-noise weights -> nl_stack_set_weights
+ * (stack.go:241-253).  noise_out: n_frames floats or NULL. */
+int nl_stack_weights_from_noise(nl_stack_t *h, float *noise_out);
+
+/* ---- 3x3 spatial median filter (internal/median/median3x3.go:26-110) ----
+ * host in/out, width*height floats each; border rows/columns copied. */
+int nl_median_filter_3x3(const float *in_host, float *out_host, int width, int height, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,13 @@
+"""nightlight_amd -- MI355X (gfx950) implementation of Nightlight's per-pixel
+stacking hot path behind the C ABI in include/nlstack.h.
+
+The product is libnlstack.so (hand-written HIP kernels + C ABI, csrc/); the
+Python modules here are plumbing for tests, bench.py and multi-GPU sharding.
+"""
+from . import capi  # noqa: F401
+from .capi import (NlError, ST_AUTO, ST_LINEAR_FIT, ST_MAD_SIGMA, ST_MEAN, ST_MEDIAN,  # noqa: F401
+                   ST_SIGMA, ST_WINSOR_SIGMA, WEIGHT_EXPOSURE, WEIGHT_INVERSE_HFR,
+                   WEIGHT_INVERSE_NOISE, WEIGHT_NONE)
+from .stack import StackHandle, median_filter_3x3, weights_from_scalars  # noqa: F401
+
+__version__ = "0.1.0"

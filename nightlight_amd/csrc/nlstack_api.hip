@@ -1,0 +1,546 @@
+// nlstack_api.hip -- the C ABI of libnlstack.so (include/nlstack.h): handle
+// management, uploads, one-pass stacking, goal-seek, per-frame statistics.
+// Host-side restatement of the bookkeeping in OpStack.Apply
+// (internal/ops/stack/stack.go:115-227); all pixel arithmetic runs in the HIP
+// kernels of this directory.  There is no CPU fallback: without a HIP device
+// every compute entry point fails with NL_ERR_NO_DEVICE / NL_ERR_HIP.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "stack_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define NL_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(NL_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+
+constexpr int kStatBlocks = 2048;
+
+int next_pow2(int n)
+{
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+}  // namespace
+
+struct nl_stack {
+    int device = 0;
+    int n_frames = 0, width = 0, height = 0, row0 = 0, rows = 0;
+    int64_t npix = 0;                 // rows*width
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    float *d_frames_owned = nullptr;  // [n_frames][npix]
+    float *d_frames = nullptr;        // owned or lent
+    float *d_out = nullptr;           // [npix]
+    float *d_acc = nullptr;           // stack-of-stacks accumulator, lazily allocated
+    float *d_weights = nullptr;       // [n_frames]
+    bool has_weights = false;
+    float *d_xstat = nullptr;         // [(n_frames+1)*2]
+    unsigned long long *d_partial = nullptr;   // [max_grid][2]
+    unsigned long long *d_counters = nullptr;  // [2]
+    double *d_stat_partial = nullptr;          // [kStatBlocks*3]
+    int max_grid = 0;
+    int last_mode = -1;
+    bool last_has_counters = false;
+    bool pending = false;
+    const char *last_kernel = "";
+};
+
+extern "C" {
+
+const char *nl_last_error(void) { return g_err.c_str(); }
+
+const char *nl_version(void) { return "nlstack 0.1.0 (gfx950)"; }
+
+int nl_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(NL_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+static int destroy_impl(nl_stack_t *h)
+{
+    if (!h) return NL_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->d_frames_owned) (void)hipFree(h->d_frames_owned);
+    if (h->d_out) (void)hipFree(h->d_out);
+    if (h->d_acc) (void)hipFree(h->d_acc);
+    if (h->d_weights) (void)hipFree(h->d_weights);
+    if (h->d_xstat) (void)hipFree(h->d_xstat);
+    if (h->d_partial) (void)hipFree(h->d_partial);
+    if (h->d_counters) (void)hipFree(h->d_counters);
+    if (h->d_stat_partial) (void)hipFree(h->d_stat_partial);
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return NL_OK;
+}
+
+void nl_stack_destroy(nl_stack_t *h) { destroy_impl(h); }
+
+static int create_impl(nl_stack_t *h)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(NL_ERR_NO_DEVICE, "no HIP device available (%s); libnlstack has no CPU path",
+                    hipGetErrorString(e));
+    if (h->device < 0 || h->device >= ndev)
+        return fail(NL_ERR_INVALID_ARG, "device %d out of range (have %d)", h->device, ndev);
+    NL_HIP(hipSetDevice(h->device));
+    NL_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    NL_HIP(hipEventCreate(&h->ev_start));
+    NL_HIP(hipEventCreate(&h->ev_stop));
+    const size_t frame_bytes = (size_t)h->npix * sizeof(float);
+    NL_HIP(hipMalloc(&h->d_frames_owned, frame_bytes * (size_t)h->n_frames));
+    h->d_frames = h->d_frames_owned;
+    NL_HIP(hipMalloc(&h->d_out, frame_bytes));
+    NL_HIP(hipMalloc(&h->d_weights, sizeof(float) * (size_t)h->n_frames));
+    h->max_grid = 256 * 64;
+    NL_HIP(hipMalloc(&h->d_partial, sizeof(unsigned long long) * 2 * (size_t)h->max_grid));
+    NL_HIP(hipMalloc(&h->d_counters, sizeof(unsigned long long) * 2));
+    NL_HIP(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * 2, h->stream));
+    NL_HIP(hipMalloc(&h->d_stat_partial, sizeof(double) * 3 * kStatBlocks));
+
+    // stats.MeanStdDev over xs = 0..n-1 (stats.go:246-261, called from :570)
+    // depends on n only: tabulate it once, in the same fp32 operation order.
+    std::vector<float> xstat(2 * (size_t)(h->n_frames + 1), 0.0f);
+    for (int n = 1; n <= h->n_frames; n++) {
+        volatile float s = 0.0f;
+        for (int i = 0; i < n; i++) s = s + (float)i;
+        const float mean = s / (float)n;
+        volatile float v = 0.0f;
+        for (int i = 0; i < n; i++) {
+            volatile float d = (float)i - mean;
+            volatile float dd = d * d;
+            v = v + dd;
+        }
+        const float var = v / (float)n;
+        xstat[2 * (size_t)n] = mean;
+        xstat[2 * (size_t)n + 1] = (float)sqrt((double)var);
+    }
+    NL_HIP(hipMalloc(&h->d_xstat, xstat.size() * sizeof(float)));
+    NL_HIP(hipMemcpy(h->d_xstat, xstat.data(), xstat.size() * sizeof(float), hipMemcpyHostToDevice));
+    return NL_OK;
+}
+
+nl_stack_t *nl_stack_create(int n_frames, int width, int height, int row0, int rows, int device)
+{
+    if (n_frames <= 0) { fail(NL_ERR_NO_INPUTS, "stack operator needs inputs"); return nullptr; }
+    if (width <= 0 || height <= 0 || row0 < 0 || rows <= 0 || row0 + rows > height) {
+        fail(NL_ERR_INVALID_ARG, "bad geometry %dx%d rows [%d,%d)", width, height, row0, row0 + rows);
+        return nullptr;
+    }
+    nl_stack_t *h = new nl_stack();
+    h->device = device; h->n_frames = n_frames; h->width = width; h->height = height;
+    h->row0 = row0; h->rows = rows; h->npix = (int64_t)rows * width;
+    if (create_impl(h) != NL_OK) {
+        std::string keep = g_err;
+        destroy_impl(h);
+        g_err = keep;
+        return nullptr;
+    }
+    return h;
+}
+
+#define NL_CHECK_HANDLE(h)                                              \
+    do {                                                                \
+        if (!(h)) return fail(NL_ERR_INVALID_ARG, "null handle");       \
+        NL_HIP(hipSetDevice((h)->device));                              \
+    } while (0)
+
+int nl_stack_upload_frame(nl_stack_t *h, int idx, const float *host_frame)
+{
+    NL_CHECK_HANDLE(h);
+    if (idx < 0 || idx >= h->n_frames || !host_frame)
+        return fail(NL_ERR_INVALID_ARG, "upload_frame: bad index %d or null frame", idx);
+    return nl_stack_upload_tile(h, idx, host_frame + (int64_t)h->row0 * h->width);
+}
+
+int nl_stack_upload_tile(nl_stack_t *h, int idx, const float *host_tile)
+{
+    NL_CHECK_HANDLE(h);
+    if (idx < 0 || idx >= h->n_frames || !host_tile)
+        return fail(NL_ERR_INVALID_ARG, "upload_tile: bad index %d or null tile", idx);
+    NL_HIP(hipMemcpyAsync(h->d_frames + (int64_t)idx * h->npix, host_tile,
+                          (size_t)h->npix * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    NL_HIP(hipStreamSynchronize(h->stream));   // pointer must not be retained (cgo rules)
+    return NL_OK;
+}
+
+int nl_stack_download_tile(nl_stack_t *h, int idx, float *host_tile)
+{
+    NL_CHECK_HANDLE(h);
+    if (idx < 0 || idx >= h->n_frames || !host_tile)
+        return fail(NL_ERR_INVALID_ARG, "download_tile: bad index %d or null tile", idx);
+    NL_HIP(hipMemcpyAsync(host_tile, h->d_frames + (int64_t)idx * h->npix,
+                          (size_t)h->npix * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    NL_HIP(hipStreamSynchronize(h->stream));
+    return NL_OK;
+}
+
+void *nl_stack_frames_device_ptr(nl_stack_t *h) { return h ? h->d_frames : nullptr; }
+void *nl_stack_result_device_ptr(nl_stack_t *h) { return h ? h->d_out : nullptr; }
+int nl_stack_last_mode(nl_stack_t *h) { return h ? h->last_mode : -1; }
+const char *nl_stack_last_kernel_name(nl_stack_t *h) { return h ? h->last_kernel : ""; }
+
+int nl_stack_attach_device_frames(nl_stack_t *h, void *device_frames)
+{
+    NL_CHECK_HANDLE(h);
+    h->d_frames = device_frames ? static_cast<float *>(device_frames) : h->d_frames_owned;
+    return NL_OK;
+}
+
+int nl_stack_fill_synthetic(nl_stack_t *h, uint64_t seed)
+{
+    NL_CHECK_HANDLE(h);
+    NL_HIP(nl::launch_fill_synthetic(h->d_frames, h->npix, h->n_frames, h->width, h->height,
+                                     h->row0, h->rows, seed, h->stream));
+    NL_HIP(hipStreamSynchronize(h->stream));
+    return NL_OK;
+}
+
+int nl_stack_set_weights(nl_stack_t *h, const float *weights)
+{
+    NL_CHECK_HANDLE(h);
+    if (!weights) { h->has_weights = false; return NL_OK; }
+    NL_HIP(hipMemcpyAsync(h->d_weights, weights, sizeof(float) * (size_t)h->n_frames,
+                          hipMemcpyHostToDevice, h->stream));
+    NL_HIP(hipStreamSynchronize(h->stream));
+    h->has_weights = true;
+    return NL_OK;
+}
+
+// getWeights, stack.go:231-270 (scalar host arithmetic, fp32, same order)
+int nl_weights_from_scalars(int weighting, const float *per_frame, int n_frames,
+                            float *weights_out, int *bad_index)
+{
+    if (bad_index) *bad_index = -1;
+    if (weighting == NL_WEIGHT_NONE) return NL_OK;
+    if (!per_frame || !weights_out || n_frames <= 0)
+        return fail(NL_ERR_INVALID_ARG, "weights_from_scalars: null argument");
+    if (weighting == NL_WEIGHT_EXPOSURE) {
+        for (int i = 0; i < n_frames; i++) {
+            if (per_frame[i] == 0) {
+                if (bad_index) *bad_index = i;
+                return fail(NL_ERR_MISSING_EXPOSURE,
+                            "%d: Missing exposure information for exposure-weighted stacking", i);
+            }
+            weights_out[i] = per_frame[i];
+        }
+        return NL_OK;
+    }
+    if (weighting == NL_WEIGHT_INVERSE_NOISE || weighting == NL_WEIGHT_INVERSE_HFR) {
+        float mn = 3.40282346638528859811704183484516925440e+38f, mx = -mn;
+        for (int i = 0; i < n_frames; i++) {
+            const float v = per_frame[i];
+            if (v < mn) mn = v;
+            if (v > mx) mx = v;
+        }
+        const float range = mx - mn;
+        for (int i = 0; i < n_frames; i++) {
+            volatile float num = per_frame[i] - mn;
+            num = 4.0f * num;
+            volatile float q = num / range;
+            volatile float den = 1.0f + q;
+            weights_out[i] = 1.0f / den;
+        }
+        return NL_OK;
+    }
+    return fail(NL_ERR_INVALID_WEIGHTING, "Invalid weighting mode %d\n", weighting);
+}
+
+static int auto_select_mode(int l)   // stack.go:45-55
+{
+    if (l >= 25) return NL_ST_LINEAR_FIT;
+    if (l >= 15) return NL_ST_WINSOR_SIGMA;
+    if (l >= 6) return NL_ST_SIGMA;
+    return NL_ST_MEAN;
+}
+
+int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_high, float ref_loc)
+{
+    NL_CHECK_HANDLE(h);
+    if (mode < NL_ST_MEDIAN || mode > NL_ST_AUTO) return fail(NL_ERR_INVALID_MODE, "invalid stacking mode");
+    if (mode == NL_ST_AUTO) mode = auto_select_mode(h->n_frames);
+    bool weighted = h->has_weights;
+    if (mode == NL_ST_MAD_SIGMA && weighted)
+        return fail(NL_ERR_WEIGHTED_MAD, "MADSigma stacking with weights is still unimplemented");
+    if (mode == NL_ST_LINEAR_FIT || mode == NL_ST_MEDIAN) weighted = false;  // stack.go:158,188-189
+
+    nl::StackArgs a;
+    a.frames = h->d_frames;
+    a.stride = h->npix;
+    a.npix = h->npix;
+    a.n_frames = h->n_frames;
+    a.n_pad = next_pow2(h->n_frames);
+    a.weights = weighted ? h->d_weights : nullptr;
+    a.xstat = h->d_xstat;
+    a.sig_lo = sigma_low; a.sig_hi = sigma_high; a.ref_loc = ref_loc;
+    a.out = h->d_out;
+    a.partial = h->d_partial;
+    a.tiles = 0;
+
+    NL_HIP(hipEventRecord(h->ev_start, h->stream));
+    if (mode == NL_ST_MEAN) {
+        NL_HIP(nl::launch_stack_mean(weighted, a, h->stream, &h->last_kernel));
+        h->last_has_counters = false;
+    } else {
+        int lanes = 0;
+        size_t lds = 0;
+        if (nl::exact_plan(mode, weighted, a.n_frames, a.n_pad, &lanes, &lds) != 0)
+            return fail(NL_ERR_TOO_MANY_FRAMES,
+                        "%d frames do not fit the per-pixel LDS column (mode %d)", a.n_frames, mode);
+        a.tiles = (a.npix + lanes - 1) / lanes;
+        int grid = (int)(a.tiles < (int64_t)h->max_grid ? a.tiles : (int64_t)h->max_grid);
+        NL_HIP(nl::launch_stack_exact(mode, weighted, a, lanes, grid, lds, h->stream, &h->last_kernel));
+        NL_HIP(nl::launch_reduce_counters(h->d_partial, grid, h->d_counters, h->stream));
+        h->last_has_counters = (mode != NL_ST_MEDIAN);
+    }
+    NL_HIP(hipEventRecord(h->ev_stop, h->stream));
+    h->last_mode = mode;
+    h->pending = true;
+    return NL_OK;
+}
+
+int nl_stack_finish(nl_stack_t *h, float *out_host, int64_t *clip_low, int64_t *clip_high)
+{
+    NL_CHECK_HANDLE(h);
+    unsigned long long c[2] = {0, 0};
+    if (h->last_has_counters && (clip_low || clip_high))
+        NL_HIP(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    if (out_host)
+        NL_HIP(hipMemcpyAsync(out_host + (int64_t)h->row0 * h->width, h->d_out,
+                              (size_t)h->npix * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    NL_HIP(hipStreamSynchronize(h->stream));
+    h->pending = false;
+    if (clip_low) *clip_low = (int64_t)c[0];
+    if (clip_high) *clip_high = (int64_t)c[1];
+    return NL_OK;
+}
+
+int nl_stack_run(nl_stack_t *h, int mode, float sigma_low, float sigma_high, float ref_loc,
+                 float *out_host, int64_t *clip_low, int64_t *clip_high)
+{
+    int rc = nl_stack_run_async(h, mode, sigma_low, sigma_high, ref_loc);
+    if (rc != NL_OK) return rc;
+    return nl_stack_finish(h, out_host, clip_low, clip_high);
+}
+
+float nl_stack_last_kernel_ms(nl_stack_t *h)
+{
+    if (!h || !h->ev_start) return -1.0f;
+    if (hipSetDevice(h->device) != hipSuccess) return -1.0f;
+    if (hipEventSynchronize(h->ev_stop) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, h->ev_start, h->ev_stop) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+// stackfindsigma.go:48-98 (commented-out reference code = the spec)
+int nl_stack_find_sigmas(nl_stack_t *h, int mode, float ref_loc,
+                         float clip_perc_low, float clip_perc_high,
+                         nl_reduce_fn reduce, void *user,
+                         float *out_host, int64_t *clip_low, int64_t *clip_high,
+                         float *sigma_low, float *sigma_high, int *passes)
+{
+    NL_CHECK_HANDLE(h);
+    if (mode == NL_ST_AUTO) mode = auto_select_mode(h->n_frames);
+    if (mode != NL_ST_SIGMA && mode != NL_ST_WINSOR_SIGMA)
+        return fail(NL_ERR_INVALID_MODE, "goal-seek bisection supports sigma and winsorized sigma only");
+    float low_left = 1.0f, low_right = 11.0f, low_mid = 0.5f * (low_left + low_right);
+    float high_left = 1.0f, high_right = 11.0f, high_mid = 0.5f * (high_left + high_right);
+    const float total = (float)((int64_t)h->width * h->height * (int64_t)h->n_frames);
+    int n_pass = 0;
+    for (int i = 0;; i++) {
+        int64_t c[2] = {0, 0};
+        int rc = nl_stack_run(h, mode, low_mid, high_mid, ref_loc, nullptr, &c[0], &c[1]);
+        if (rc != NL_OK) return rc;
+        n_pass++;
+        if (reduce) {
+            rc = reduce(c, user);
+            if (rc != 0) return fail(NL_ERR_INVALID_ARG, "counter reduction callback failed (%d)", rc);
+        }
+        const float perc_l = (float)c[0] * 100.0f / total;
+        const float perc_h = (float)c[1] * 100.0f / total;
+        const int delta_l = (int)(100 * perc_l + 0.5f) - (int)(100 * clip_perc_low);
+        const int delta_h = (int)(100 * perc_h + 0.5f) - (int)(100 * clip_perc_high);
+        if ((delta_l == 0 && delta_h == 0) || i >= 20) {
+            if (clip_low) *clip_low = c[0];
+            if (clip_high) *clip_high = c[1];
+            if (sigma_low) *sigma_low = low_mid;
+            if (sigma_high) *sigma_high = high_mid;
+            if (passes) *passes = n_pass;
+            if (out_host) return nl_stack_finish(h, out_host, nullptr, nullptr);
+            return NL_OK;
+        }
+        if (delta_l > 0) { low_left = low_mid; low_mid = 0.5f * (low_left + low_right); }
+        else if (delta_l < 0) { low_right = low_mid; low_mid = 0.5f * (low_left + low_right); }
+        if (delta_h > 0) { high_left = high_mid; high_mid = 0.5f * (high_left + high_right); }
+        else if (delta_h < 0) { high_right = high_mid; high_mid = 0.5f * (high_left + high_right); }
+    }
+}
+
+// StackIncremental / StackIncrementalFinalize, stack.go:924-944
+int nl_stack_accumulate(nl_stack_t *h, float weight, int first)
+{
+    NL_CHECK_HANDLE(h);
+    if (!h->d_acc) NL_HIP(hipMalloc(&h->d_acc, (size_t)h->npix * sizeof(float)));
+    NL_HIP(nl::launch_axpy(h->d_acc, h->d_out, weight, first, h->npix, h->stream));
+    NL_HIP(hipStreamSynchronize(h->stream));
+    return NL_OK;
+}
+
+int nl_stack_accumulate_finalize(nl_stack_t *h, float weight_sum, float *out_host)
+{
+    NL_CHECK_HANDLE(h);
+    if (!h->d_acc) return fail(NL_ERR_INVALID_ARG, "accumulate_finalize before accumulate");
+    volatile float factor = 1.0f / weight_sum;
+    NL_HIP(nl::launch_scale(h->d_acc, factor, h->npix, h->stream));
+    if (out_host)
+        NL_HIP(hipMemcpyAsync(out_host + (int64_t)h->row0 * h->width, h->d_acc,
+                              (size_t)h->npix * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    NL_HIP(hipStreamSynchronize(h->stream));
+    return NL_OK;
+}
+
+// ---- per-frame statistics ---------------------------------------------------
+
+static int frame_stats_impl(nl_stack_t *h, const float *d, int64_t n, float *mn, float *mean,
+                            float *mx, double *variance)
+{
+    std::vector<double> part(3 * kStatBlocks);
+    NL_HIP(nl::launch_min_sum_max(d, n, h->d_stat_partial, kStatBlocks, h->stream));
+    NL_HIP(hipMemcpyAsync(part.data(), h->d_stat_partial, sizeof(double) * 3 * kStatBlocks,
+                          hipMemcpyDeviceToHost, h->stream));
+    NL_HIP(hipStreamSynchronize(h->stream));
+    float lo = (float)part[0], hi = (float)part[2];
+    double sum = 0.0;
+    for (int b = 0; b < kStatBlocks; b++) {
+        const float bl = (float)part[3 * b], bh = (float)part[3 * b + 2];
+        if (bl < lo) lo = bl;
+        if (bh > hi) hi = bh;
+        sum += part[3 * b + 1];
+    }
+    const float m = (float)(sum / (double)n);
+    if (mn) *mn = lo;
+    if (mx) *mx = hi;
+    if (mean) *mean = m;
+    if (variance) {
+        NL_HIP(nl::launch_variance(d, n, m, h->d_stat_partial, kStatBlocks, h->stream));
+        NL_HIP(hipMemcpyAsync(part.data(), h->d_stat_partial, sizeof(double) * kStatBlocks,
+                              hipMemcpyDeviceToHost, h->stream));
+        NL_HIP(hipStreamSynchronize(h->stream));
+        double s = 0.0;
+        for (int b = 0; b < kStatBlocks; b++) s += part[b];
+        *variance = s / (double)n;
+    }
+    return NL_OK;
+}
+
+int nl_stack_frame_stats(nl_stack_t *h, int idx, float *mn, float *mean, float *mx,
+                         double *variance)
+{
+    NL_CHECK_HANDLE(h);
+    if (idx < 0 || idx >= h->n_frames) return fail(NL_ERR_INVALID_ARG, "frame_stats: bad index %d", idx);
+    return frame_stats_impl(h, h->d_frames + (int64_t)idx * h->npix, h->npix, mn, mean, mx, variance);
+}
+
+static int frame_noise_impl(nl_stack_t *h, const float *d, float *noise)
+{
+    std::vector<double> part(kStatBlocks);
+    NL_HIP(nl::launch_noise(d, h->width, h->height, h->d_stat_partial, kStatBlocks, h->stream));
+    NL_HIP(hipMemcpyAsync(part.data(), h->d_stat_partial, sizeof(double) * kStatBlocks,
+                          hipMemcpyDeviceToHost, h->stream));
+    NL_HIP(hipStreamSynchronize(h->stream));
+    double s = 0.0;
+    for (int b = 0; b < kStatBlocks; b++) s += part[b];
+    // noise.go:53: factor = float32(sqrt(pi/2)) / (6*float32(w-2)*float32(h-2)), fp32
+    const float c = (float)sqrt(0.5 * M_PI);
+    volatile float den = 6.0f * (float)(h->width - 2);
+    den = den * (float)(h->height - 2);
+    const float factor = c / den;
+    *noise = (float)s * factor;
+    return NL_OK;
+}
+
+int nl_stack_frame_noise(nl_stack_t *h, int idx, float *noise)
+{
+    NL_CHECK_HANDLE(h);
+    if (idx < 0 || idx >= h->n_frames || !noise)
+        return fail(NL_ERR_INVALID_ARG, "frame_noise: bad index %d or null output", idx);
+    if (h->row0 != 0 || h->rows != h->height)
+        return fail(NL_ERR_INVALID_ARG, "frame_noise needs a whole-image handle (3x3 stencil)");
+    if (h->width < 3 || h->height < 3) return fail(NL_ERR_INVALID_ARG, "frame_noise: image too small");
+    return frame_noise_impl(h, h->d_frames + (int64_t)idx * h->npix, noise);
+}
+
+int nl_stack_weights_from_noise(nl_stack_t *h, float *noise_out)
+{
+    NL_CHECK_HANDLE(h);
+    std::vector<float> noise((size_t)h->n_frames), w((size_t)h->n_frames);
+    for (int i = 0; i < h->n_frames; i++) {
+        int rc = nl_stack_frame_noise(h, i, &noise[(size_t)i]);
+        if (rc != NL_OK) return rc;
+    }
+    if (noise_out) memcpy(noise_out, noise.data(), sizeof(float) * noise.size());
+    int rc = nl_weights_from_scalars(NL_WEIGHT_INVERSE_NOISE, noise.data(), h->n_frames, w.data(), nullptr);
+    if (rc != NL_OK) return rc;
+    return nl_stack_set_weights(h, w.data());
+}
+
+int nl_median_filter_3x3(const float *in_host, float *out_host, int width, int height, int device)
+{
+    if (!in_host || !out_host || width < 1 || height < 1)
+        return fail(NL_ERR_INVALID_ARG, "median_filter_3x3: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(NL_ERR_NO_DEVICE, "no HIP device available; libnlstack has no CPU path");
+    NL_HIP(hipSetDevice(device));
+    const size_t bytes = (size_t)width * height * sizeof(float);
+    float *d_in = nullptr, *d_out = nullptr;
+    NL_HIP(hipMalloc(&d_in, bytes));
+    hipError_t e = hipMalloc(&d_out, bytes);
+    if (e != hipSuccess) { (void)hipFree(d_in); return fail(NL_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    int rc = NL_OK;
+    do {
+        if ((e = hipMemcpy(d_in, in_host, bytes, hipMemcpyHostToDevice)) != hipSuccess) break;
+        if ((e = nl::launch_median3x3(d_in, d_out, width, height, nullptr)) != hipSuccess) break;
+        if ((e = hipMemcpy(out_host, d_out, bytes, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    } while (0);
+    if (e != hipSuccess) rc = fail(NL_ERR_HIP, "median_filter_3x3: %s", hipGetErrorString(e));
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+}  // extern "C"

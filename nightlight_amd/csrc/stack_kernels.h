@@ -1,0 +1,64 @@
+// stack_kernels.h -- shared declarations of libnlstack's HIP kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/nlstack.h"
+
+namespace nl {
+
+// 160 KiB LDS per CU (MI355X); a single workgroup may use all of it.
+constexpr size_t kLdsBudgetBytes = 160 * 1024;
+
+struct StackArgs {
+    const float *frames;          // planar [n_frames][stride] fp32
+    int64_t stride;               // floats between consecutive frames (= tile pixels)
+    int64_t npix;                 // pixels in the tile
+    int64_t tiles;                // work items (wave tiles) in the launch
+    int n_frames;
+    int n_pad;                    // next power of two >= n_frames (sorting modes)
+    const float *weights;         // device, n_frames floats, or nullptr
+    const float *xstat;           // device, [n_frames+1][2]: MeanStdDev of 0..n-1 (linear fit)
+    float sig_lo, sig_hi, ref_loc;
+    float *out;                   // [npix]
+    unsigned long long *partial;  // [grid][2] clip counters per workgroup
+};
+
+// ---- stack_exact.hip ----
+// Picks lanes-per-wave and LDS bytes for the exact kernel; -1 if it cannot fit.
+int exact_plan(int mode, bool weighted, int n_frames, int n_pad, int *lanes, size_t *lds_bytes);
+hipError_t launch_stack_exact(int mode, bool weighted, StackArgs &args, int lanes, int grid,
+                              size_t lds_bytes, hipStream_t stream, const char **name);
+hipError_t launch_reduce_counters(const unsigned long long *partial, int n_blocks,
+                                  unsigned long long *counters, hipStream_t stream);
+
+// ---- stack_mean.hip ----
+hipError_t launch_stack_mean(bool weighted, const StackArgs &args, hipStream_t stream,
+                             const char **name);
+hipError_t launch_axpy(float *acc, const float *x, float weight, int first, int64_t n,
+                       hipStream_t stream);
+hipError_t launch_scale(float *acc, float factor, int64_t n, hipStream_t stream);
+
+// ---- synth.hip ----
+hipError_t launch_fill_synthetic(float *frames, int64_t stride, int n_frames, int width,
+                                 int height, int row0, int rows, uint64_t seed,
+                                 hipStream_t stream);
+
+// ---- frame_stats.hip ----
+struct FrameStatsOut {            // device scratch written by the stats kernels
+    float mn, mx;
+    double sum;
+    double sumsq;
+    double noise_sum;
+};
+hipError_t launch_min_sum_max(const float *data, int64_t n, double *partial /*[blocks][3]*/,
+                              int blocks, hipStream_t stream);
+hipError_t launch_variance(const float *data, int64_t n, float mean, double *partial /*[blocks]*/,
+                           int blocks, hipStream_t stream);
+hipError_t launch_noise(const float *data, int width, int height, double *partial /*[blocks]*/,
+                        int blocks, hipStream_t stream);
+hipError_t launch_median3x3(const float *in, float *out, int width, int height,
+                            hipStream_t stream);
+
+}  // namespace nl

@@ -1,0 +1,202 @@
+"""Thin Python view of one nl_stack_t handle (include/nlstack.h).
+
+Used by the tests, bench.py and the row-tile sharding helper; every method is
+one C-ABI call.  Naming follows the reference's domain: frames, tiles, stack
+passes, clip counters (internal/ops/stack/stack.go).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class StackHandle:
+    """Frames of one row tile [row0, row0+rows) resident in HBM as planar
+    [n_frames][rows*width] fp32, plus the result tile and clip counters."""
+
+    def __init__(self, n_frames, width, height, row0=0, rows=None, device=0):
+        self._lib = capi.load()
+        rows = height - row0 if rows is None else rows
+        self.n_frames, self.width, self.height = int(n_frames), int(width), int(height)
+        self.row0, self.rows, self.device = int(row0), int(rows), int(device)
+        self._h = self._lib.nl_stack_create(self.n_frames, self.width, self.height,
+                                            self.row0, self.rows, self.device)
+        if not self._h:
+            raise capi.NlError(capi.ERR_HIP, capi.last_error())
+
+    # -- lifecycle ---------------------------------------------------------
+    def close(self):
+        if self._h:
+            self._lib.nl_stack_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def tile_pixels(self):
+        return self.rows * self.width
+
+    # -- frames ------------------------------------------------------------
+    def upload_frame(self, idx, frame):
+        """frame: full image, width*height float32 (fits.Image.Data)."""
+        frame = np.ascontiguousarray(frame, dtype=np.float32).reshape(-1)
+        assert frame.size == self.width * self.height
+        capi.check(self._lib.nl_stack_upload_frame(self._h, int(idx), capi.fptr(frame)))
+
+    def upload_tile(self, idx, tile):
+        tile = np.ascontiguousarray(tile, dtype=np.float32).reshape(-1)
+        assert tile.size == self.tile_pixels
+        capi.check(self._lib.nl_stack_upload_tile(self._h, int(idx), capi.fptr(tile)))
+
+    def upload_frames(self, frames):
+        for i, f in enumerate(frames):
+            self.upload_frame(i, f)
+
+    def download_tile(self, idx):
+        out = np.empty(self.tile_pixels, np.float32)
+        capi.check(self._lib.nl_stack_download_tile(self._h, int(idx), capi.fptr(out)))
+        return out
+
+    def fill_synthetic(self, seed=0x4E4C5354):
+        capi.check(self._lib.nl_stack_fill_synthetic(self._h, C.c_uint64(seed)))
+
+    def frames_device_ptr(self):
+        return self._lib.nl_stack_frames_device_ptr(self._h)
+
+    def attach_device_frames(self, ptr):
+        capi.check(self._lib.nl_stack_attach_device_frames(self._h, C.c_void_p(ptr)))
+
+    def set_weights(self, weights):
+        if weights is None:
+            capi.check(self._lib.nl_stack_set_weights(self._h, None))
+            return
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        assert w.size == self.n_frames
+        capi.check(self._lib.nl_stack_set_weights(self._h, capi.fptr(w)))
+
+    # -- stack passes ------------------------------------------------------
+    def run(self, mode, sigma_low=2.75, sigma_high=2.75, ref_loc=0.0, out=None, fetch=True):
+        """One pass. Returns (result or None, clip_low, clip_high).  `out` is a
+        full-image float32 array whose tile rows get written; with fetch=False
+        the result stays on the device."""
+        cl, ch = C.c_int64(0), C.c_int64(0)
+        if fetch and out is None:
+            out = np.zeros(self.width * self.height, np.float32)
+        optr = capi.fptr(out) if (fetch and out is not None) else None
+        capi.check(self._lib.nl_stack_run(self._h, int(mode), C.c_float(sigma_low),
+                                          C.c_float(sigma_high), C.c_float(ref_loc), optr,
+                                          C.byref(cl), C.byref(ch)))
+        return (out if fetch else None), cl.value, ch.value
+
+    def run_async(self, mode, sigma_low=2.75, sigma_high=2.75, ref_loc=0.0):
+        capi.check(self._lib.nl_stack_run_async(self._h, int(mode), C.c_float(sigma_low),
+                                                C.c_float(sigma_high), C.c_float(ref_loc)))
+
+    def finish(self, out=None):
+        cl, ch = C.c_int64(0), C.c_int64(0)
+        capi.check(self._lib.nl_stack_finish(self._h, capi.fptr(out) if out is not None else None,
+                                             C.byref(cl), C.byref(ch)))
+        return cl.value, ch.value
+
+    def result_tile(self):
+        """The result tile only (rows*width), downloaded from the device."""
+        full = np.zeros(self.width * self.height, np.float32)
+        self.finish(full)
+        return full[self.row0 * self.width:(self.row0 + self.rows) * self.width].copy()
+
+    @property
+    def last_mode(self):
+        return self._lib.nl_stack_last_mode(self._h)
+
+    @property
+    def last_kernel_ms(self):
+        return float(self._lib.nl_stack_last_kernel_ms(self._h))
+
+    @property
+    def last_kernel_name(self):
+        return self._lib.nl_stack_last_kernel_name(self._h).decode()
+
+    def find_sigmas(self, mode, clip_perc_low, clip_perc_high, ref_loc=0.0, reduce=None,
+                    fetch=True):
+        """Goal-seek bisection (stackfindsigma.go:48-98).  `reduce(lo, hi) ->
+        (lo, hi)` maps this tile's counters to the totals over all tiles."""
+        cl, ch = C.c_int64(0), C.c_int64(0)
+        sl, sh, passes = C.c_float(), C.c_float(), C.c_int()
+        out = np.zeros(self.width * self.height, np.float32) if fetch else None
+
+        def _cb(counters, _user):
+            try:
+                lo, hi = reduce(int(counters[0]), int(counters[1]))
+                counters[0], counters[1] = int(lo), int(hi)
+                return 0
+            except Exception:   # never unwind through the C frame
+                return 1
+
+        cb = capi.REDUCE_FN(_cb) if reduce is not None else C.cast(None, capi.REDUCE_FN)
+        capi.check(self._lib.nl_stack_find_sigmas(
+            self._h, int(mode), C.c_float(ref_loc), C.c_float(clip_perc_low),
+            C.c_float(clip_perc_high), cb, None, capi.fptr(out) if fetch else None,
+            C.byref(cl), C.byref(ch), C.byref(sl), C.byref(sh), C.byref(passes)))
+        return out, cl.value, ch.value, float(sl.value), float(sh.value), passes.value
+
+    # -- stack of stacks ---------------------------------------------------
+    def accumulate(self, weight, first):
+        capi.check(self._lib.nl_stack_accumulate(self._h, C.c_float(weight), int(bool(first))))
+
+    def accumulate_finalize(self, weight_sum):
+        out = np.zeros(self.width * self.height, np.float32)
+        capi.check(self._lib.nl_stack_accumulate_finalize(self._h, C.c_float(weight_sum),
+                                                          capi.fptr(out)))
+        return out
+
+    # -- per-frame statistics ----------------------------------------------
+    def frame_stats(self, idx, variance=True):
+        mn, mean, mx = C.c_float(), C.c_float(), C.c_float()
+        var = C.c_double()
+        capi.check(self._lib.nl_stack_frame_stats(self._h, int(idx), C.byref(mn), C.byref(mean),
+                                                  C.byref(mx), C.byref(var) if variance else None))
+        return (np.float32(mn.value), np.float32(mean.value), np.float32(mx.value),
+                float(var.value) if variance else None)
+
+    def frame_noise(self, idx):
+        v = C.c_float()
+        capi.check(self._lib.nl_stack_frame_noise(self._h, int(idx), C.byref(v)))
+        return np.float32(v.value)
+
+    def weights_from_noise(self):
+        noise = np.zeros(self.n_frames, np.float32)
+        capi.check(self._lib.nl_stack_weights_from_noise(self._h, capi.fptr(noise)))
+        return noise
+
+
+def weights_from_scalars(weighting, per_frame):
+    """getWeights (stack.go:231-270) on per-frame exposure / noise / HFR."""
+    lib = capi.load()
+    pf = np.ascontiguousarray(per_frame, dtype=np.float32)
+    w = np.zeros(pf.size, np.float32)
+    bad = C.c_int(-1)
+    rc = lib.nl_weights_from_scalars(int(weighting), capi.fptr(pf), pf.size, capi.fptr(w),
+                                     C.byref(bad))
+    if rc != capi.OK:
+        raise capi.NlError(rc, capi.last_error())
+    return None if weighting == capi.WEIGHT_NONE else w
+
+
+def median_filter_3x3(image, width, height, device=0):
+    lib = capi.load()
+    src = np.ascontiguousarray(image, dtype=np.float32).reshape(-1)
+    dst = np.empty_like(src)
+    capi.check(lib.nl_median_filter_3x3(capi.fptr(src), capi.fptr(dst), int(width), int(height),
+                                        int(device)))
+    return dst

@@ -1,0 +1,188 @@
+"""GPU parity: every stacking mode through the C ABI (libnlstack.so) against
+the CPU oracle on the same seeded inputs.  Bar: result bit-identical as fp32
+values, clip counters equal (integers).  Mirrors the mode dispatch of
+OpStack.Apply, internal/ops/stack/stack.go:156-190."""
+import numpy as np
+import pytest
+
+from util import describe_mismatch, make_frames, same_values
+
+pytestmark = pytest.mark.gpu
+
+MODES = {0: "median", 1: "mean", 2: "sigma", 3: "winsor", 4: "mad", 5: "linearfit"}
+
+
+def run_both(nl, oracle, mode, frames, width, height, weights, sl, sh, ref_loc=0.0):
+    n = frames.shape[0]
+    with nl.StackHandle(n, width, height) as st:
+        st.upload_frames(frames)
+        st.set_weights(weights)
+        got, cl, ch = st.run(mode, sl, sh, ref_loc)
+    ow = None if mode in (0, 5) else weights
+    rc, want, wl, wh, _ = oracle.stack_apply(mode, frames, ow, sl, sh, ref_loc, num_cpu=4)
+    assert rc == 0
+    return got, (cl, ch), want, (wl, wh)
+
+
+@pytest.mark.parametrize("mode", sorted(MODES))
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 15, 25, 64, 128])
+def test_mode_matches_oracle(nl, oracle, mode, n):
+    width, height = 67, 29            # 1943 pixels: ragged vs 64-lane tiles and vs float4
+    frames = make_frames(n, width, height, seed=100 + n)
+    got, gc, want, wc = run_both(nl, oracle, mode, frames, width, height, None, 2.75, 2.75)
+    assert same_values(got, want), "%s n=%d: %s" % (MODES[mode], n, describe_mismatch(got, want))
+    if mode >= 2:
+        assert gc == wc, "%s n=%d clip counters %r vs oracle %r" % (MODES[mode], n, gc, wc)
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("n", [2, 7, 16, 33, 128])
+def test_weighted_modes_match_oracle(nl, oracle, mode, n):
+    width, height = 64, 31
+    frames = make_frames(n, width, height, seed=200 + n)
+    rng = np.random.default_rng(n)
+    weights = (0.2 + 0.8 * rng.random(n)).astype(np.float32)
+    got, gc, want, wc = run_both(nl, oracle, mode, frames, width, height, weights, 2.0, 3.0)
+    assert same_values(got, want), "%s weighted n=%d: %s" % (MODES[mode], n, describe_mismatch(got, want))
+    if mode >= 2:
+        assert gc == wc
+
+
+@pytest.mark.parametrize("mode", [0, 2, 3, 4, 5])
+def test_ties_and_asymmetric_sigmas(nl, oracle, mode):
+    width, height = 50, 20
+    frames = make_frames(40, width, height, seed=77, ties=True)
+    got, gc, want, wc = run_both(nl, oracle, mode, frames, width, height, None, 1.0, 4.0)
+    assert same_values(got, want), describe_mismatch(got, want)
+    if mode >= 2:
+        assert gc == wc
+
+
+def test_ref_frame_loc_fills_pixels_without_data(nl, oracle):
+    # stack.go:388-397: a pixel that is NaN in every frame gets RefFrameLoc
+    width, height = 16, 8
+    frames = make_frames(9, width, height, seed=5)
+    for mode in range(6):
+        got, _, want, _ = run_both(nl, oracle, mode, frames, width, height, None, 2.75, 2.75,
+                                   ref_loc=123.5)
+        empty = np.isnan(frames).all(axis=0)
+        assert empty.any()
+        assert np.all(got[empty] == np.float32(123.5))
+        assert same_values(got, want)
+
+
+def test_linear_fit_and_median_ignore_weights(nl, oracle):
+    # stack.go:158 and :188-189: weights are computed, then not passed
+    width, height = 32, 8
+    frames = make_frames(30, width, height, seed=9)
+    w = np.linspace(0.2, 1.0, 30).astype(np.float32)
+    for mode in (0, 5):
+        got_w, c_w, want, wc = run_both(nl, oracle, mode, frames, width, height, w, 2.75, 2.75)
+        assert same_values(got_w, want)
+        if mode == 5:
+            assert c_w == wc
+
+
+def test_weighted_mad_is_an_error_not_a_panic(nl):
+    from nightlight_amd import capi
+    with nl.StackHandle(8, 16, 4) as st:
+        st.upload_frames(make_frames(8, 16, 4, seed=1))
+        st.set_weights(np.ones(8, np.float32))
+        with pytest.raises(capi.NlError) as e:
+            st.run(4, 2.0, 2.0)
+        assert e.value.code == capi.ERR_WEIGHTED_MAD
+        assert "MADSigma stacking with weights" in e.value.message
+
+
+def test_invalid_mode(nl):
+    from nightlight_amd import capi
+    with nl.StackHandle(4, 8, 4) as st:
+        for bad in (-1, 7):
+            with pytest.raises(capi.NlError) as e:
+                st.run(bad)
+            assert e.value.code == capi.ERR_INVALID_MODE
+            assert e.value.message == "invalid stacking mode"
+
+
+def test_auto_mode_selection(nl, oracle):
+    # stack.go:45-55
+    for n, expect in ((3, 1), (6, 2), (15, 3), (25, 5)):
+        frames = make_frames(n, 16, 8, seed=n)
+        with nl.StackHandle(n, 16, 8) as st:
+            st.upload_frames(frames)
+            got, cl, ch = st.run(6, 2.75, 2.75)
+            assert st.last_mode == expect
+        rc, want, wl, wh, mu = oracle.stack_apply(6, frames, None, 2.75, 2.75)
+        assert mu == expect and same_values(got, want) and (cl, ch) == (wl, wh)
+
+
+def test_infinite_samples_are_data(nl, oracle):
+    # math.IsNaN is the only filter (quirk Q11): +-Inf samples take part
+    width, height = 16, 4
+    frames = make_frames(12, width, height, seed=3, nan_frac=0.0, nan_border=False,
+                         all_nan_patch=False)
+    frames[2, 5] = np.inf
+    frames[3, 9] = -np.inf
+    for mode in (0, 1, 2, 4, 5):
+        got, gc, want, wc = run_both(nl, oracle, mode, frames, width, height, None, 2.75, 2.75)
+        assert same_values(got, want), "mode %d: %s" % (mode, describe_mismatch(got, want))
+        if mode >= 2:
+            assert gc == wc
+
+
+def test_negative_sigma_degenerates_like_the_reference(nl, oracle):
+    # quirk Q6: sigma=-1 inverts the bounds, first pass clips everything
+    width, height = 32, 4
+    frames = make_frames(10, width, height, seed=4)
+    got, gc, want, wc = run_both(nl, oracle, 2, frames, width, height, None, -1.0, -1.0)
+    assert same_values(got, want) and gc == wc
+
+
+def test_tiles_reassemble_the_whole_image(nl, oracle):
+    # row-tile sharding: per-tile results and counters add up
+    width, height, n = 40, 24, 20
+    frames = make_frames(n, width, height, seed=11)
+    rc, want, wl, wh, _ = oracle.stack_apply(3, frames, None, 2.5, 2.5)
+    out = np.zeros(width * height, np.float32)
+    tl = th = 0
+    for row0, rows in ((0, 7), (7, 9), (16, 8)):
+        with nl.StackHandle(n, width, height, row0=row0, rows=rows) as st:
+            st.upload_frames(frames)
+            _, cl, ch = st.run(3, 2.5, 2.5, out=out)
+            tl += cl
+            th += ch
+    assert same_values(out, want) and (tl, th) == (wl, wh)
+
+
+def test_synthetic_fill_is_tile_consistent_and_deterministic(nl):
+    width, height, n = 48, 36, 11
+    with nl.StackHandle(n, width, height) as st:
+        st.fill_synthetic(1234)
+        whole = np.stack([st.download_tile(i) for i in range(n)])
+        st.fill_synthetic(1234)
+        again = np.stack([st.download_tile(i) for i in range(n)])
+    assert np.array_equal(whole.view(np.uint32), again.view(np.uint32))
+    with nl.StackHandle(n, width, height, row0=10, rows=12) as st:
+        st.fill_synthetic(1234)
+        part = np.stack([st.download_tile(i) for i in range(n)])
+    ref = whole.reshape(n, height, width)[:, 10:22, :].reshape(n, -1)
+    assert np.array_equal(part.view(np.uint32), ref.view(np.uint32))
+    assert np.isnan(whole).all(axis=0).sum() == 64          # the 8x8 patch without data
+    assert 0.001 < np.isnan(whole).mean() < 0.5
+
+
+def test_larger_stack_sigma_and_goal_seek(nl, oracle):
+    # a 256x96 stack of 48 frames: sigma clip, then the bisection goal-seek
+    width, height, n = 256, 96, 48
+    with nl.StackHandle(n, width, height) as st:
+        st.fill_synthetic(99)
+        frames = np.stack([st.download_tile(i) for i in range(n)])
+        got, cl, ch = st.run(2, 3.0, 3.0)
+        rc, want, wl, wh, _ = oracle.stack_apply(2, frames, None, 3.0, 3.0, num_cpu=8)
+        assert same_values(got, want), describe_mismatch(got, want)
+        assert (cl, ch) == (wl, wh)
+        out, cl, ch, sl, sh, passes = st.find_sigmas(2, 0.5, 0.5)
+        op, ores, ocl, och, osl, osh = oracle.find_sigmas_bisect(2, frames, 0.5, 0.5, num_cpu=8)
+        assert (passes, cl, ch) == (op, ocl, och)
+        assert (np.float32(sl), np.float32(sh)) == (osl, osh)
+        assert same_values(out, ores)

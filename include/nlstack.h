@@ -123,6 +123,14 @@ int nl_stack_last_mode(nl_stack_t *h);
 /* GPU time of the last pass's kernels in ms, from HIP events recorded on the
  * handle's stream around the launches (valid after finish/run). */
 float nl_stack_last_kernel_ms(nl_stack_t *h);
+/* on != 0: run every mode with the bit-exact kernels only (per-pixel replay
+ * of the reference's permutation; slow, used for verification).  Default 0:
+ * sigma clipping uses the register-resident kernel, which keeps the clip
+ * counters identical to the reference's and the output within summation-order
+ * rounding, and hands undecidable pixels to the exact kernel. */
+int nl_stack_set_exact(nl_stack_t *h, int on);
+/* Pixels of the last pass that were re-done by the exact kernel. */
+int64_t nl_stack_last_fallback_pixels(nl_stack_t *h);
 /* Name of the dominant kernel launched by the last pass (for profiles). */
 const char *nl_stack_last_kernel_name(nl_stack_t *h);
 

@@ -35,6 +35,7 @@ EXPORTS = [
     "nl_stack_set_weights", "nl_weights_from_scalars",
     "nl_stack_run", "nl_stack_run_async", "nl_stack_finish", "nl_stack_result_device_ptr",
     "nl_stack_last_mode", "nl_stack_last_kernel_ms", "nl_stack_last_kernel_name",
+    "nl_stack_set_exact", "nl_stack_last_fallback_pixels",
     "nl_stack_find_sigmas", "nl_stack_accumulate", "nl_stack_accumulate_finalize",
     "nl_stack_frame_stats", "nl_stack_frame_noise", "nl_stack_weights_from_noise",
     "nl_median_filter_3x3",
@@ -96,6 +97,9 @@ def load():
     L.nl_stack_last_kernel_ms.restype = C.c_float
     L.nl_stack_last_kernel_name.argtypes = [vp]
     L.nl_stack_last_kernel_name.restype = C.c_char_p
+    L.nl_stack_set_exact.argtypes = [vp, C.c_int]
+    L.nl_stack_last_fallback_pixels.argtypes = [vp]
+    L.nl_stack_last_fallback_pixels.restype = C.c_int64
     L.nl_stack_find_sigmas.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, REDUCE_FN,
                                        vp, _f32p, _i64p, _i64p, _f32p, _f32p, _intp]
     L.nl_stack_accumulate.argtypes = [vp, C.c_float, C.c_int]

@@ -38,6 +38,7 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 constexpr int kStatBlocks = 2048;
+constexpr int kListGrid = 2048;     // workgroups of the exact kernel in fallback-list mode
 
 int next_pow2(int n)
 {
@@ -61,7 +62,13 @@ struct nl_stack {
     float *d_weights = nullptr;       // [n_frames]
     bool has_weights = false;
     float *d_xstat = nullptr;         // [(n_frames+1)*2]
-    unsigned long long *d_partial = nullptr;   // [max_grid][2]
+    unsigned long long *d_partial = nullptr;   // [partial_slots][2]
+    unsigned *d_fb_list = nullptr;             // [npix] pixels the fast kernel handed to the exact kernel
+    unsigned *d_fb_count = nullptr;            // [2]: exact-list length, generic-list length
+    unsigned *d_gen_list = nullptr;            // [npix] pixels zonal waves handed to the generic pass
+    int partial_slots = 0;
+    bool force_exact = false;
+    bool last_used_fast = false;
     unsigned long long *d_counters = nullptr;  // [2]
     double *d_stat_partial = nullptr;          // [kStatBlocks*3]
     int max_grid = 0;
@@ -96,6 +103,9 @@ static int destroy_impl(nl_stack_t *h)
     if (h->d_weights) (void)hipFree(h->d_weights);
     if (h->d_xstat) (void)hipFree(h->d_xstat);
     if (h->d_partial) (void)hipFree(h->d_partial);
+    if (h->d_fb_list) (void)hipFree(h->d_fb_list);
+    if (h->d_fb_count) (void)hipFree(h->d_fb_count);
+    if (h->d_gen_list) (void)hipFree(h->d_gen_list);
     if (h->d_counters) (void)hipFree(h->d_counters);
     if (h->d_stat_partial) (void)hipFree(h->d_stat_partial);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
@@ -126,7 +136,15 @@ static int create_impl(nl_stack_t *h)
     NL_HIP(hipMalloc(&h->d_out, frame_bytes));
     NL_HIP(hipMalloc(&h->d_weights, sizeof(float) * (size_t)h->n_frames));
     h->max_grid = 256 * 64;
-    NL_HIP(hipMalloc(&h->d_partial, sizeof(unsigned long long) * 2 * (size_t)h->max_grid));
+    const int fast_slots = nl::fast_partial_slots(h->npix);
+    h->partial_slots = (fast_slots > h->max_grid ? fast_slots : h->max_grid) + kListGrid;
+    NL_HIP(hipMalloc(&h->d_partial, sizeof(unsigned long long) * 2 * (size_t)h->partial_slots));
+    if (h->npix < (int64_t)0xFFFFFFFFll) {
+        NL_HIP(hipMalloc(&h->d_fb_list, sizeof(unsigned) * (size_t)h->npix));
+        NL_HIP(hipMalloc(&h->d_gen_list, sizeof(unsigned) * (size_t)h->npix));
+        NL_HIP(hipMalloc(&h->d_fb_count, 2 * sizeof(unsigned)));
+        NL_HIP(hipMemsetAsync(h->d_fb_count, 0, 2 * sizeof(unsigned), h->stream));
+    }
     NL_HIP(hipMalloc(&h->d_counters, sizeof(unsigned long long) * 2));
     NL_HIP(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * 2, h->stream));
     NL_HIP(hipMalloc(&h->d_stat_partial, sizeof(double) * 3 * kStatBlocks));
@@ -309,15 +327,49 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
     a.out = h->d_out;
     a.partial = h->d_partial;
     a.tiles = 0;
+    a.list = nullptr;
+    a.list_count = nullptr;
+    a.list_capacity = 0;
 
     NL_HIP(hipEventRecord(h->ev_start, h->stream));
     if (mode == NL_ST_MEAN) {
         NL_HIP(nl::launch_stack_mean(weighted, a, h->stream, &h->last_kernel));
         h->last_has_counters = false;
-    } else {
+    } else if (!h->force_exact && h->d_fb_list && nl::fast_supported(mode, weighted, a.n_frames)) {
+        // register-resident fast kernel; pixels it cannot decide go to the exact kernel
+        nl::FastArgs f;
+        f.fb_list = h->d_fb_list;
+        f.fb_count = h->d_fb_count;
+        f.fb_capacity = (unsigned)h->npix;
+        f.gen_list = h->d_gen_list;
+        f.gen_count = h->d_fb_count + 1;
+        f.gen_capacity = (unsigned)h->npix;
+        f.in_list = nullptr;
+        f.in_count = nullptr;
+        f.in_capacity = 0;
+        NL_HIP(hipMemsetAsync(h->d_fb_count, 0, 2 * sizeof(unsigned), h->stream));
+        int fast_grid = 0;
+        NL_HIP(nl::launch_stack_sigma_fast(a, f, &fast_grid, h->stream, &h->last_kernel));
         int lanes = 0;
         size_t lds = 0;
-        if (nl::exact_plan(mode, weighted, a.n_frames, a.n_pad, &lanes, &lds) != 0)
+        if (nl::exact_plan(mode, weighted, a.n_frames, a.n_pad, 16, &lanes, &lds) != 0)
+            return fail(NL_ERR_TOO_MANY_FRAMES,
+                        "%d frames do not fit the per-pixel LDS column (mode %d)", a.n_frames, mode);
+        nl::StackArgs e = a;
+        e.list = h->d_fb_list;
+        e.list_count = h->d_fb_count;
+        e.list_capacity = (unsigned)h->npix;
+        e.partial = h->d_partial + 2 * (size_t)fast_grid;
+        const char *exact_name = "";
+        NL_HIP(nl::launch_stack_exact(mode, weighted, e, lanes, kListGrid, lds, h->stream, &exact_name));
+        NL_HIP(nl::launch_reduce_counters(h->d_partial, fast_grid + kListGrid, h->d_counters, h->stream));
+        h->last_has_counters = true;
+        h->last_used_fast = true;
+    } else {
+        h->last_used_fast = false;
+        int lanes = 0;
+        size_t lds = 0;
+        if (nl::exact_plan(mode, weighted, a.n_frames, a.n_pad, 64, &lanes, &lds) != 0)
             return fail(NL_ERR_TOO_MANY_FRAMES,
                         "%d frames do not fit the per-pixel LDS column (mode %d)", a.n_frames, mode);
         a.tiles = (a.npix + lanes - 1) / lanes;
@@ -354,6 +406,23 @@ int nl_stack_run(nl_stack_t *h, int mode, float sigma_low, float sigma_high, flo
     int rc = nl_stack_run_async(h, mode, sigma_low, sigma_high, ref_loc);
     if (rc != NL_OK) return rc;
     return nl_stack_finish(h, out_host, clip_low, clip_high);
+}
+
+int nl_stack_set_exact(nl_stack_t *h, int on)
+{
+    NL_CHECK_HANDLE(h);
+    h->force_exact = on != 0;
+    return NL_OK;
+}
+
+int64_t nl_stack_last_fallback_pixels(nl_stack_t *h)
+{
+    if (!h || !h->last_used_fast || !h->d_fb_count) return 0;
+    if (hipSetDevice(h->device) != hipSuccess) return -1;
+    unsigned c = 0;
+    if (hipMemcpyAsync(&c, h->d_fb_count, sizeof c, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+    return (int64_t)c;
 }
 
 float nl_stack_last_kernel_ms(nl_stack_t *h)

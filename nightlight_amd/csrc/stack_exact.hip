@@ -78,6 +78,15 @@ __device__ float select_median(Col<S> a, int n)
     return res;
 }
 
+// float32(math.Sqrt(float64(x))) (stats.go:259): square root in fp64, rounded
+// once to fp32 = the correctly rounded fp32 root.  NOT __fsqrt_rn: without
+// OCML_BASIC_ROUNDED_OPERATIONS HIP maps that to the 1-ulp native v_sqrt_f32,
+// which flipped one clip decision in 2.1e9 samples against the oracle.
+__device__ __forceinline__ float sqrt_like_go(float x)
+{
+    return (float)__builtin_sqrt((double)x);
+}
+
 // stats.go:246-261
 template <int S>
 __device__ void mean_stddev(Col<S> a, int n, float &mean, float &sd)
@@ -93,7 +102,7 @@ __device__ void mean_stddev(Col<S> a, int n, float &mean, float &sd)
     }
     v = v / fn;
     mean = m;
-    sd = __fsqrt_rn(v);
+    sd = sqrt_like_go(v);
 }
 
 // stack.go:411-424 (+ :494-511 with the mirrored weight column)
@@ -168,7 +177,7 @@ __device__ float winsorized_stddev(Col<S> a, int n, float median, float sd)
         }
         v = v / fn;
         const float old = sd;
-        sd = 1.134f * __fsqrt_rn(v);
+        sd = 1.134f * sqrt_like_go(v);
         const float factor = fabsf(sd - old) / old;
         if (changed == 0 || factor <= 0.0005f) break;
     }
@@ -220,9 +229,18 @@ __global__ __launch_bounds__(64) void stack_exact_kernel(StackArgs p)
 
     int c_lo = 0, c_hi = 0;
 
-    for (int64_t tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
-        const int64_t pix = tile * LANES + lane;
-        const bool on = lane_on && pix < p.npix;
+    // list mode: redo only the pixels a fast kernel could not decide
+    int64_t limit = p.npix, tiles = p.tiles;
+    if (p.list) {
+        const unsigned cnt = *p.list_count;
+        limit = cnt < p.list_capacity ? cnt : p.list_capacity;
+        tiles = (limit + LANES - 1) / LANES;
+    }
+
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t idx = tile * LANES + lane;
+        const bool on = lane_on && idx < limit;
+        const int64_t pix = p.list ? (int64_t)p.list[on ? idx : 0] : idx;
         const float *fr = p.frames + (on ? pix : 0);
 
         // ---- gather (stack.go:380-387): frame order, NaN dropped ----
@@ -412,12 +430,14 @@ static hipError_t launch_exact_lanes(StackArgs &args, int lanes, int grid, size_
     }
 }
 
-int exact_plan(int mode, bool weighted, int n_frames, int n_pad, int *lanes, size_t *lds_bytes)
+int exact_plan(int mode, bool weighted, int n_frames, int n_pad, int max_lanes, int *lanes,
+               size_t *lds_bytes)
 {
     const int columns = ((mode == NL_ST_MAD_SIGMA) ||
                          (weighted && (mode == NL_ST_SIGMA || mode == NL_ST_WINSOR_SIGMA))) ? 2 : 1;
     const size_t n_alloc = (mode == NL_ST_LINEAR_FIT) ? (size_t)n_pad : (size_t)n_frames;
     for (int l = 64; l >= 16; l >>= 1) {
+        if (l > max_lanes) continue;
         const size_t bytes = (size_t)columns * n_alloc * l * sizeof(float);
         if (bytes <= kLdsBudgetBytes) {
             *lanes = l;

@@ -1,0 +1,460 @@
+// stack_fast.hip -- register-resident sigma-clip kernels for gfx950 (MI355X).
+//
+// One pixel per lane, the pixel's N samples in VGPRs (static indices only).
+// A sorting network orders them once; after that the median is a lookup,
+// clipping removes a prefix / suffix of the sorted column, and every later
+// iteration of StackSigma (internal/ops/stack/stack.go:401-431) is a couple of
+// passes over registers -- no LDS, no data-dependent addressing, no divergence
+// inside a pass.  HBM traffic: each sample is read exactly once (4*(N+1) B per
+// output pixel), 256 contiguous bytes per wave per frame.
+//
+// Exactness contract.  The reference computes mean / stddev as sequential fp32
+// sums over a data-dependent permutation (qsort.go:94-126 leaves it, stats.go
+// :246-261 sums over it), so its stddev cannot be reproduced bit for bit
+// without replaying the permutation.  These kernels instead
+//   * take the median exactly (order independent),
+//   * compute mean~ / var~ in their own order and bracket the reference's
+//     stddev in a rigorous interval [s_min, s_max] that holds for ANY summation
+//     order (standard forward error bound),
+//   * evaluate the reference's bound expressions median -/+ sigma*stddev at
+//     both interval ends with the reference's own fp32 operations, and
+//   * accept a clip decision only if it is the same at both ends.
+// A pixel with any undecidable sample (a sample inside the few-ulp window, or
+// an infinite sample) is appended to the "exact" list and re-done from scratch
+// by the bit-exact kernel (stack_exact.hip).  Hence: clip counters are
+// identical to the reference's, and the output mean differs only by summation
+// order (<= ~1e-6 relative).
+//
+// Two instantiations per network size.  ZONAL: valid while every lane of the
+// wave misses at most kPadMax samples and has clipped fewer than kZone samples
+// per side; then only the kZone lowest and kZone+kPadMax highest sorted
+// positions can ever be excluded and all other positions are summed without a
+// mask.  A wave that leaves this regime (NaN borders, heavy clipping) puts its
+// pixels on the "generic" list; the GENERIC instantiation re-does those from
+// the list with every position masked by its rank.
+#include <type_traits>
+#include <utility>
+
+#include "stack_kernels.h"
+
+namespace nl {
+
+constexpr float kU = 5.9604644775390625e-8f;   // 2^-24, fp32 unit roundoff
+constexpr int kZone = 8;      // sorted positions per side that may be clipped in the zonal path
+constexpr int kPadMax = 8;    // missing samples (NaN) a lane may have in the zonal path
+
+// compile-time loops: every index is a constant, so register columns never
+// fall back to scratch memory (pragma unroll gives up on the large networks)
+template <int B, int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f)
+{
+    (f(std::integral_constant<int, B + I>{}), ...);
+}
+template <int B, int E, class F>
+__device__ __forceinline__ void static_range(F &&f)
+{
+    if constexpr (E > B) static_for_impl<B>(std::make_integer_sequence<int, E - B>{}, static_cast<F &&>(f));
+}
+// same, but the instruction scheduler may not move code across chunk
+// boundaries: keeps the live ranges of per-element temporaries (lane masks,
+// scalar addresses, differences) short in these very long basic blocks
+template <int B, int E, int CH, class F>
+__device__ __forceinline__ void static_chunks(F &&f)
+{
+    if constexpr (E > B) {
+        constexpr int M = (B + CH < E) ? B + CH : E;
+        static_for_impl<B>(std::make_integer_sequence<int, M - B>{}, f);
+        __builtin_amdgcn_sched_barrier(0);
+        static_chunks<M, E, CH>(static_cast<F &&>(f));
+    }
+}
+#define NL_INL __attribute__((always_inline))
+
+// ---- Batcher odd-even merge sort, generated at compile time -----------------
+// All comparators put the minimum at the lower index, so comparators touching
+// an index >= NS can simply be dropped: the network sorts NS elements for any
+// NS (not only powers of two).
+struct CePair { short lo, hi; };
+
+template <int NS>
+struct OemNetwork {
+    static constexpr int pow2()
+    {
+        int p = 1;
+        while (p < NS) p <<= 1;
+        return p;
+    }
+    static constexpr int count()
+    {
+        int c = 0;
+        const int P2 = pow2();
+        for (int p = 1; p < P2; p <<= 1)
+            for (int k = p; k >= 1; k >>= 1)
+                for (int j = k % p; j + k < P2; j += 2 * k)
+                    for (int i = 0; i < k; i++)
+                        if ((i + j) / (2 * p) == (i + j + k) / (2 * p) && (i + j + k) < NS) c++;
+        return c;
+    }
+    static constexpr int kCount = count();
+    struct Table { CePair e[kCount > 0 ? kCount : 1]; };
+    static constexpr Table make()
+    {
+        Table t{};
+        int c = 0;
+        const int P2 = pow2();
+        for (int p = 1; p < P2; p <<= 1)
+            for (int k = p; k >= 1; k >>= 1)
+                for (int j = k % p; j + k < P2; j += 2 * k)
+                    for (int i = 0; i < k; i++)
+                        if ((i + j) / (2 * p) == (i + j + k) / (2 * p) && (i + j + k) < NS) {
+                            t.e[c].lo = (short)(i + j);
+                            t.e[c].hi = (short)(i + j + k);
+                            c++;
+                        }
+        return t;
+    }
+    static constexpr Table kTable = make();
+};
+
+template <int NS>
+__device__ __forceinline__ void sort_network(float (&v)[NS])
+{
+    using Net = OemNetwork<NS>;
+    static_chunks<0, Net::kCount, 64>([&](auto I) NL_INL {
+        constexpr CePair ce = Net::kTable.e[decltype(I)::value];
+        const float lo = fminf(v[ce.lo], v[ce.hi]);
+        const float hi = fmaxf(v[ce.lo], v[ce.hi]);
+        v[ce.lo] = lo;
+        v[ce.hi] = hi;
+    });
+}
+
+// value at a per-lane position idx, known to lie in [B, E)
+template <int B, int E, int NS>
+__device__ __forceinline__ float pick(const float (&v)[NS], int idx)
+{
+    float r = v[B];
+    static_range<B + 1, E>([&](auto K) NL_INL {
+        constexpr int k = decltype(K)::value;
+        r = (idx == k) ? v[k] : r;
+    });
+    return r;
+}
+
+// the compiler must not share the 'rank in [a,b)' masks between passes: 128
+// live lane masks would spill the SGPR file
+__device__ __forceinline__ int opaque(int x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// ZONAL = true : grid covers the tile, lane = pixel blockIdx*256+thread;
+// ZONAL = false: grid-stride over q.in_list (pixels handed over by the zonal
+//                kernel), any number of missing / clipped samples.
+template <int NS, bool ZONAL>
+__global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
+{
+    static_assert(!ZONAL || NS >= 48, "zonal passes need room between the zones");
+    constexpr int ZL = kZone;                                 // low zone  = positions [0, ZL)
+    constexpr int ZH = ZONAL ? NS - kZone - kPadMax : NS;     // high zone = positions [ZH, NS)
+    const int N = p.n_frames;
+
+    int c_lo_total = 0, c_hi_total = 0;
+    // one item per lane, no loop (a loop would let the compiler hoist the 128
+    // per-frame scalar address selects out of it and spill them).  ZONAL, or
+    // GENERIC without a list: item = tile pixel; GENERIC with a list: item =
+    // position in the hand-over list (workgroups beyond its length exit).
+    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool listed = !ZONAL && q.in_list != nullptr;
+    const int64_t limit = listed ? (int64_t)min(*q.in_count, q.in_capacity) : p.npix;
+    const bool wg_has_work = (int64_t)blockIdx.x * blockDim.x < limit;
+
+    if (wg_has_work) {
+        const bool on = item < limit;
+        int64_t pix = item;
+        if (listed) pix = on ? (int64_t)q.in_list[item] : 0;
+        const unsigned boff = (unsigned)(on ? pix : 0) * 4u;     // byte offset inside a frame
+
+        // ---- gather: all loads first (independent, 256 B per wave each); the
+        // frame pointer advances by one frame per position and stops at the
+        // last frame, so unused positions (k >= N) re-read a valid address ----
+        float v[NS];
+        {
+            const char *fk = reinterpret_cast<const char *>(p.frames);
+            const int64_t frame_bytes = p.stride * (int64_t)sizeof(float);
+            static_chunks<0, NS, 16>([&](auto K) NL_INL {
+                constexpr int k = decltype(K)::value;
+                v[k] = *reinterpret_cast<const float *>(fk + boff);
+                fk += (k + 1 < N) ? frame_bytes : 0;
+            });
+        }
+        // NaN = no data (stack.go:380-387): NaNs and unused positions become
+        // +Inf and sort last; a genuine +-Inf sample sends the pixel to the
+        // exact kernel
+        int nan_cnt = 0, nonfinite_cnt = 0;
+        static_chunks<0, NS, 16>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            float x = v[k];
+            x = (k < N) ? x : __builtin_nanf("");
+            nan_cnt += (x != x) ? 1 : 0;
+            nonfinite_cnt += !(fabsf(x) < __builtin_inff()) ? 1 : 0;
+            v[k] = fminf(x, __builtin_inff());          // minnum(NaN, Inf) = Inf
+        });
+        const int n = NS - nan_cnt;
+        bool to_exact = nonfinite_cnt != nan_cnt;
+        sort_network<NS>(v);
+
+        float res = p.ref_loc;
+        int c_lo = 0, c_hi = 0;
+        int a = 0, b = n;                       // surviving samples = sorted positions [a, b)
+        bool active = on && n > 0 && !to_exact;
+        bool to_generic = false;
+        if constexpr (ZONAL) {
+            // zonal passes need b > ZH (and a < ZL) for every active lane
+            if (!__all(!active || (n > ZH))) {
+                to_generic = active;
+                active = false;
+            }
+        }
+
+        while (__any(active)) {
+            const int cnt = b - a;
+            const float fcnt = (float)cnt;
+            float m, var, amax;
+            if constexpr (ZONAL) {
+                // ---- mean~: unmasked middle, masked zones ----
+                float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                static_range<0, ZL>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    s0 += (k >= a) ? v[k] : 0.0f;
+                });
+                static_chunks<0, (ZH - ZL) / 4, 8>([&](auto K) NL_INL {
+                    constexpr int k = ZL + 4 * decltype(K)::value;
+                    s0 += v[k]; s1 += v[k + 1]; s2 += v[k + 2]; s3 += v[k + 3];
+                });
+                static_range<ZH, NS>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    s1 += (k < b) ? v[k] : 0.0f;
+                });
+                m = ((s0 + s1) + (s2 + s3)) / fcnt;
+                float q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+                static_range<0, ZL>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    const float d = (k >= a) ? v[k] - m : 0.0f;
+                    q0 = __builtin_fmaf(d, d, q0);
+                });
+                static_chunks<0, (ZH - ZL) / 4, 4>([&](auto K) NL_INL {
+                    constexpr int k = ZL + 4 * decltype(K)::value;
+                    const float d0 = v[k] - m, d1 = v[k + 1] - m, d2 = v[k + 2] - m, d3 = v[k + 3] - m;
+                    q0 = __builtin_fmaf(d0, d0, q0); q1 = __builtin_fmaf(d1, d1, q1);
+                    q2 = __builtin_fmaf(d2, d2, q2); q3 = __builtin_fmaf(d3, d3, q3);
+                });
+                static_range<ZH, NS>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    const float d = (k < b) ? v[k] - m : 0.0f;
+                    q1 = __builtin_fmaf(d, d, q1);
+                });
+                var = ((q0 + q1) + (q2 + q3)) / fcnt;
+                // sorted: max|x| of the survivors is at one of the two ends
+                amax = fmaxf(fabsf(pick<0, ZL>(v, a)), fabsf(pick<ZH, NS>(v, b - 1)));
+            } else {
+                const int a1 = opaque(a);
+                float s0 = 0, s1 = 0, s2 = 0, s3 = 0, sa = 0;
+                static_chunks<0, NS / 4, 2>([&](auto K) NL_INL {
+                    constexpr int k = 4 * decltype(K)::value;
+                    const float x0 = ((unsigned)(k + 0 - a1) < (unsigned)cnt) ? v[k + 0] : 0.0f;
+                    const float x1 = ((unsigned)(k + 1 - a1) < (unsigned)cnt) ? v[k + 1] : 0.0f;
+                    const float x2 = ((unsigned)(k + 2 - a1) < (unsigned)cnt) ? v[k + 2] : 0.0f;
+                    const float x3 = ((unsigned)(k + 3 - a1) < (unsigned)cnt) ? v[k + 3] : 0.0f;
+                    s0 += x0; s1 += x1; s2 += x2; s3 += x3;
+                    sa = fmaxf(fmaxf(sa, fabsf(x0)), fabsf(x1));
+                    sa = fmaxf(fmaxf(sa, fabsf(x2)), fabsf(x3));
+                });
+                m = ((s0 + s1) + (s2 + s3)) / fcnt;
+                amax = sa;
+                const int a2 = opaque(a);
+                float q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+                static_chunks<0, NS / 4, 2>([&](auto K) NL_INL {
+                    constexpr int k = 4 * decltype(K)::value;
+                    const float d0 = ((unsigned)(k + 0 - a2) < (unsigned)cnt) ? v[k + 0] - m : 0.0f;
+                    const float d1 = ((unsigned)(k + 1 - a2) < (unsigned)cnt) ? v[k + 1] - m : 0.0f;
+                    const float d2 = ((unsigned)(k + 2 - a2) < (unsigned)cnt) ? v[k + 2] - m : 0.0f;
+                    const float d3 = ((unsigned)(k + 3 - a2) < (unsigned)cnt) ? v[k + 3] - m : 0.0f;
+                    q0 = __builtin_fmaf(d0, d0, q0); q1 = __builtin_fmaf(d1, d1, q1);
+                    q2 = __builtin_fmaf(d2, d2, q2); q3 = __builtin_fmaf(d3, d3, q3);
+                });
+                var = ((q0 + q1) + (q2 + q3)) / fcnt;
+            }
+
+            // ---- bracket the reference's stddev ----
+            // relative slack on the variance: reference gamma_(n+3), ours, margins
+            const float eps = (fcnt + 64.0f) * kU;
+            // |reference mean - true mean| <= gamma_n * mean|x| <= e_m
+            const float e_m = 1.02f * (fcnt + 2.0f) * kU * amax;
+            // |our mean - true mean| <= gamma_(NS/4+24) * mean|x| <= e_o
+            const float e_o = 1.02f * ((float)(NS / 4 + 24)) * kU * amax;
+            const float v_hi = var + var * eps + e_m * e_m;
+            const float v_lo = fmaxf(var - var * eps - e_o * e_o, 0.0f);
+            const float s_max = __fsqrt_rn(v_hi) * (1.0f + 4.0f * kU);
+            const float s_min = __fsqrt_rn(v_lo) * (1.0f - 4.0f * kU);
+            bool bail = !(v_hi < 3.0e38f);          // overflow / NaN: exact kernel
+
+            // ---- exact median (qsort.go:68-82): sorted column, position lookup ----
+            const int kk = a + (cnt >> 1);
+            // zonal: a in [0,ZL), b in (ZH,NS]  =>  kk in [ZH/2, ZL-1+NS/2]
+            constexpr int W0 = ZONAL ? ZH / 2 - 1 : 0, W1 = ZONAL ? ZL + NS / 2 + 1 : NS;
+            const float upper = pick<W0, W1>(v, kk);
+            const float lower = pick<W0, W1>(v, kk - 1);
+            const float median = (cnt & 1) ? upper : 0.5f * (lower + upper);
+
+            // ---- the reference's bound expressions at both ends of the interval ----
+            // (stack.go:408-409; fp32 multiply then add, never fused)
+            const float tl0 = __fmul_rn(p.sig_lo, s_min), tl1 = __fmul_rn(p.sig_lo, s_max);
+            const float th0 = __fmul_rn(p.sig_hi, s_min), th1 = __fmul_rn(p.sig_hi, s_max);
+            const float la = __fsub_rn(median, tl0), lb = __fsub_rn(median, tl1);
+            const float ha = __fadd_rn(median, th0), hb = __fadd_rn(median, th1);
+            const float lo_min = fminf(la, lb), lo_max = fmaxf(la, lb);
+            const float hi_min = fminf(ha, hb), hi_max = fmaxf(ha, hb);
+
+            // ---- count certain clips (c1,d1) and possible clips (c2,d2) ----
+            int c1 = 0, c2 = 0, d1 = 0, d2 = 0;
+            if constexpr (ZONAL) {
+                static_range<0, ZL>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    const bool in = k >= a;
+                    c1 += (in && v[k] < lo_min) ? 1 : 0;
+                    c2 += (in && v[k] < lo_max) ? 1 : 0;
+                });
+                static_range<ZH, NS>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    const bool in = k < b;
+                    d1 += (in && v[k] > hi_max) ? 1 : 0;
+                    d2 += (in && v[k] > hi_min) ? 1 : 0;
+                });
+                // the zones must still hold a survivor on each side, otherwise the
+                // next sorted position (outside the zone) might be clipped as well:
+                // the whole wave restarts these pixels in the generic kernel
+                const bool overflow = active && ((a + c2 >= ZL) || (b - d2 <= ZH));
+                if (__any(overflow)) {
+                    to_generic = active;
+                    active = false;
+                }
+            } else {
+                const int a3 = opaque(a);
+                static_chunks<0, NS, 8>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    const bool in = (unsigned)(k - a3) < (unsigned)cnt;
+                    const float x = v[k];
+                    c1 += (in && x < lo_min) ? 1 : 0;
+                    c2 += (in && x < lo_max) ? 1 : 0;
+                    d1 += (in && x > hi_max) ? 1 : 0;
+                    d2 += (in && x > hi_min) ? 1 : 0;
+                });
+            }
+            if (active) {
+                // a sample inside the window, or (negative sigma) inverted bounds where the
+                // reference's "low first" order matters: let the exact kernel decide
+                bail |= (c1 != c2) || (d1 != d2) || (lo_max > hi_min && (c1 + d1) > 0);
+                if (bail) {
+                    to_exact = true;
+                    active = false;
+                } else {
+                    c_lo += c1;
+                    c_hi += d1;
+                    a += c1;
+                    b -= d1;
+                    if ((c1 + d1) == 0 || (b - a) <= 1) {     // stack.go:427-430: mean BEFORE this pass
+                        res = m;
+                        active = false;
+                    }
+                }
+            }
+        }
+
+        if (on) {
+            if (to_generic) {
+                const unsigned slot = atomicAdd(q.gen_count, 1u);
+                if (slot < q.gen_capacity) q.gen_list[slot] = (unsigned)pix;
+            } else if (to_exact) {
+                const unsigned slot = atomicAdd(q.fb_count, 1u);
+                if (slot < q.fb_capacity) q.fb_list[slot] = (unsigned)pix;
+            } else {
+                p.out[pix] = res;
+                c_lo_total += c_lo;
+                c_hi_total += c_hi;
+            }
+        }
+    }
+
+    // clip totals: wave sum -> block sum -> one slot per workgroup
+    __shared__ int s_lo[4], s_hi[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c_lo_total += __shfl_xor(c_lo_total, o, 64);
+        c_hi_total += __shfl_xor(c_hi_total, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = c_lo_total; s_hi[threadIdx.x >> 6] = c_hi_total; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        p.partial[2 * (size_t)blockIdx.x + 0] = (unsigned long long)(s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3]);
+        p.partial[2 * (size_t)blockIdx.x + 1] = (unsigned long long)(s_hi[0] + s_hi[1] + s_hi[2] + s_hi[3]);
+    }
+}
+
+int fast_supported(int mode, bool weighted, int n_frames)
+{
+    return (mode == NL_ST_SIGMA && !weighted && n_frames >= 2 && n_frames <= 128) ? 1 : 0;
+}
+
+
+template <int NS>
+static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned tile_blocks,
+                        int *blocks_used, hipStream_t stream)
+{
+    FastArgs f = fargs;
+    f.in_list = nullptr;
+    f.in_count = nullptr;
+    f.in_capacity = 0;
+    if constexpr (NS >= 48) {
+        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true>), dim3(tile_blocks), dim3(256), 0,
+                           stream, args, f);
+        // generic pass over the pixels the zonal waves handed over
+        StackArgs g = args;
+        g.partial = args.partial + 2 * (size_t)tile_blocks;
+        f.in_list = fargs.gen_list;
+        f.in_count = fargs.gen_count;
+        f.in_capacity = fargs.gen_capacity;
+        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false>), dim3(tile_blocks), dim3(256), 0,
+                           stream, g, f);
+        *blocks_used = 2 * (int)tile_blocks;
+    } else {
+        // small stacks: generic passes are cheap, run them over the whole tile
+        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false>), dim3(tile_blocks), dim3(256), 0,
+                           stream, args, f);
+        *blocks_used = (int)tile_blocks;
+    }
+}
+
+int fast_partial_slots(int64_t npix) { return 2 * (int)((npix + 255) / 256); }
+
+hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, int *blocks_used,
+                                   hipStream_t stream, const char **name)
+{
+    const unsigned blocks = (unsigned)((args.npix + 255) / 256);
+    const int n = args.n_frames;
+    // network sizes: the frame count rounded up to the next instantiated size;
+    // unused positions count as missing samples
+    if (n <= 8)        { *name = "stack_sigma_fast_kernel<8>";   launch_pair<8>(args, fargs, blocks, blocks_used, stream); }
+    else if (n <= 16)  { *name = "stack_sigma_fast_kernel<16>";  launch_pair<16>(args, fargs, blocks, blocks_used, stream); }
+    else if (n <= 32)  { *name = "stack_sigma_fast_kernel<32>";  launch_pair<32>(args, fargs, blocks, blocks_used, stream); }
+    else if (n <= 48)  { *name = "stack_sigma_fast_kernel<48>";  launch_pair<48>(args, fargs, blocks, blocks_used, stream); }
+    else if (n <= 64)  { *name = "stack_sigma_fast_kernel<64>";  launch_pair<64>(args, fargs, blocks, blocks_used, stream); }
+    else if (n <= 80)  { *name = "stack_sigma_fast_kernel<80>";  launch_pair<80>(args, fargs, blocks, blocks_used, stream); }
+    else if (n <= 96)  { *name = "stack_sigma_fast_kernel<96>";  launch_pair<96>(args, fargs, blocks, blocks_used, stream); }
+    else if (n <= 112) { *name = "stack_sigma_fast_kernel<112>"; launch_pair<112>(args, fargs, blocks, blocks_used, stream); }
+    else               { *name = "stack_sigma_fast_kernel<128>"; launch_pair<128>(args, fargs, blocks, blocks_used, stream); }
+    return hipGetLastError();
+}
+
+}  // namespace nl

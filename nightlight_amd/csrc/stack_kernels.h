@@ -23,15 +23,38 @@ struct StackArgs {
     float sig_lo, sig_hi, ref_loc;
     float *out;                   // [npix]
     unsigned long long *partial;  // [grid][2] clip counters per workgroup
+    const unsigned *list;         // optional: pixel indices to process instead of 0..npix-1
+    const unsigned *list_count;   // device-side length of `list`
+    unsigned list_capacity;
+};
+
+// fallback list written by the fast kernels, consumed by the exact kernel
+struct FastArgs {
+    unsigned *fb_list;            // [fb_capacity] pixels for the exact kernel
+    unsigned *fb_count;           // device counter, zeroed before every pass
+    unsigned fb_capacity;
+    unsigned *gen_list;           // [gen_capacity] pixels a zonal wave hands to the generic pass
+    unsigned *gen_count;          // device counter, zeroed before every pass
+    unsigned gen_capacity;
+    const unsigned *in_list;      // generic pass: list to process (nullptr = the whole tile)
+    const unsigned *in_count;
+    unsigned in_capacity;
 };
 
 // ---- stack_exact.hip ----
 // Picks lanes-per-wave and LDS bytes for the exact kernel; -1 if it cannot fit.
-int exact_plan(int mode, bool weighted, int n_frames, int n_pad, int *lanes, size_t *lds_bytes);
+int exact_plan(int mode, bool weighted, int n_frames, int n_pad, int max_lanes, int *lanes,
+               size_t *lds_bytes);
 hipError_t launch_stack_exact(int mode, bool weighted, StackArgs &args, int lanes, int grid,
                               size_t lds_bytes, hipStream_t stream, const char **name);
 hipError_t launch_reduce_counters(const unsigned long long *partial, int n_blocks,
                                   unsigned long long *counters, hipStream_t stream);
+
+// ---- stack_fast.hip ----
+int fast_supported(int mode, bool weighted, int n_frames);
+int fast_partial_slots(int64_t npix);
+hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, int *blocks_used,
+                                   hipStream_t stream, const char **name);
 
 // ---- stack_mean.hip ----
 hipError_t launch_stack_mean(bool weighted, const StackArgs &args, hipStream_t stream,

@@ -115,6 +115,14 @@ class StackHandle:
         self.finish(full)
         return full[self.row0 * self.width:(self.row0 + self.rows) * self.width].copy()
 
+    def set_exact(self, on=True):
+        """Force the bit-exact kernels (verification); default is the fast path."""
+        capi.check(self._lib.nl_stack_set_exact(self._h, int(bool(on))))
+
+    @property
+    def last_fallback_pixels(self):
+        return int(self._lib.nl_stack_last_fallback_pixels(self._h))
+
     @property
     def last_mode(self):
         return self._lib.nl_stack_last_mode(self._h)

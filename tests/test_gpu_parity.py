@@ -12,11 +12,29 @@ pytestmark = pytest.mark.gpu
 MODES = {0: "median", 1: "mean", 2: "sigma", 3: "winsor", 4: "mad", 5: "linearfit"}
 
 
-def run_both(nl, oracle, mode, frames, width, height, weights, sl, sh, ref_loc=0.0):
+# fp32 tolerance of the north star ("within 1e-5 relative"); only the
+# register-resident sigma kernel needs it (its sums run in sorted order, the
+# reference's in quickselect order) -- everything else is bit-exact.
+RTOL = 1e-5
+
+
+def close_values(a, b, rtol=RTOL):
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    if a.shape != b.shape or not np.array_equal(np.isnan(a), np.isnan(b)):
+        return False
+    ok = ~np.isnan(a) & (a != b)          # equal values (incl. +-Inf) are fine as they are
+    return bool(np.all(np.abs(a[ok].astype(np.float64) - b[ok]) <= rtol * np.abs(b[ok].astype(np.float64))))
+
+
+def run_both(nl, oracle, mode, frames, width, height, weights, sl, sh, ref_loc=0.0, exact=True):
+    """exact=True forces the bit-exact kernels; exact=False is the default
+    dispatch (register-resident kernel for unweighted sigma clipping)."""
     n = frames.shape[0]
     with nl.StackHandle(n, width, height) as st:
         st.upload_frames(frames)
         st.set_weights(weights)
+        st.set_exact(exact)
         got, cl, ch = st.run(mode, sl, sh, ref_loc)
     ow = None if mode in (0, 5) else weights
     rc, want, wl, wh, _ = oracle.stack_apply(mode, frames, ow, sl, sh, ref_loc, num_cpu=4)
@@ -33,6 +51,31 @@ def test_mode_matches_oracle(nl, oracle, mode, n):
     assert same_values(got, want), "%s n=%d: %s" % (MODES[mode], n, describe_mismatch(got, want))
     if mode >= 2:
         assert gc == wc, "%s n=%d clip counters %r vs oracle %r" % (MODES[mode], n, gc, wc)
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 8, 9, 15, 16, 25, 33, 48, 50, 64, 65, 80, 100, 112, 127, 128])
+@pytest.mark.parametrize("kappa", [2.75, 1.5])
+def test_fast_sigma_counts_exact_values_close(nl, oracle, n, kappa):
+    # default dispatch: register-resident sigma kernel (+ generic pass on the NaN
+    # borders, + exact kernel for undecidable pixels).  Clip counters must equal the
+    # oracle's; values agree to summation-order rounding.
+    width, height = 131, 37
+    frames = make_frames(n, width, height, seed=300 + n)
+    got, gc, want, wc = run_both(nl, oracle, 2, frames, width, height, None, kappa, kappa, exact=False)
+    assert gc == wc, "fast sigma n=%d clip counters %r vs oracle %r" % (n, gc, wc)
+    assert close_values(got, want), "fast sigma n=%d: %s" % (n, describe_mismatch(got, want))
+    # the rounding difference is far below the tolerance in practice
+    ok = ~np.isnan(want) & (want != 0)
+    assert np.max(np.abs(got[ok] - want[ok]) / np.abs(want[ok])) < 2e-6
+
+
+def test_fast_sigma_clean_frames_no_nan(nl, oracle):
+    # no missing samples at all: every wave stays in the zonal passes
+    width, height, n = 256, 64, 128
+    frames = make_frames(n, width, height, seed=17, nan_frac=0.0, nan_border=False,
+                         all_nan_patch=False)
+    got, gc, want, wc = run_both(nl, oracle, 2, frames, width, height, None, 3.0, 3.0, exact=False)
+    assert gc == wc and close_values(got, want)
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3])
@@ -110,6 +153,7 @@ def test_auto_mode_selection(nl, oracle):
         frames = make_frames(n, 16, 8, seed=n)
         with nl.StackHandle(n, 16, 8) as st:
             st.upload_frames(frames)
+            st.set_exact(True)
             got, cl, ch = st.run(6, 2.75, 2.75)
             assert st.last_mode == expect
         rc, want, wl, wh, mu = oracle.stack_apply(6, frames, None, 2.75, 2.75)
@@ -136,6 +180,38 @@ def test_negative_sigma_degenerates_like_the_reference(nl, oracle):
     frames = make_frames(10, width, height, seed=4)
     got, gc, want, wc = run_both(nl, oracle, 2, frames, width, height, None, -1.0, -1.0)
     assert same_values(got, want) and gc == wc
+    # the register-resident kernel hands inverted bounds to the exact kernel
+    got, gc, want, wc = run_both(nl, oracle, 2, frames, width, height, None, -1.0, -1.0, exact=False)
+    assert close_values(got, want) and gc == wc
+    got, gc, want, wc = run_both(nl, oracle, 2, frames, width, height, None, 0.0, 3.0, exact=False)
+    assert close_values(got, want) and gc == wc
+
+
+def test_fast_sigma_hands_infinite_samples_to_the_exact_kernel(nl, oracle):
+    width, height = 64, 8
+    frames = make_frames(64, width, height, seed=31, nan_frac=0.0, nan_border=False,
+                         all_nan_patch=False)
+    frames[2, 5] = np.inf
+    frames[3, 9] = -np.inf
+    frames[7, 100] = np.inf
+    frames[8, 100] = np.inf
+    got, gc, want, wc = run_both(nl, oracle, 2, frames, width, height, None, 2.75, 2.75, exact=False)
+    assert gc == wc
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert close_values(got[ok], want[ok])
+
+
+def test_fast_sigma_constant_and_tied_pixels(nl, oracle):
+    # zero variance, heavy ties and two-valued pixels: the bound interval collapses
+    width, height, n = 64, 4, 64
+    frames = np.full((n, width * height), 1000.0, np.float32)
+    frames[:, 64:128] = (np.arange(n, dtype=np.float32) % 2)[:, None] * 8 + 500      # two values
+    frames[:, 128:192] = np.round(make_frames(n, 64, 1, seed=8, nan_frac=0, nan_border=False,
+                                              all_nan_patch=False) / 32) * 32          # ties
+    frames[5, 10] = 5000.0                                                             # one outlier
+    got, gc, want, wc = run_both(nl, oracle, 2, frames, width, height, None, 2.0, 2.0, exact=False)
+    assert gc == wc and close_values(got, want), describe_mismatch(got, want)
 
 
 def test_tiles_reassemble_the_whole_image(nl, oracle):
@@ -152,6 +228,17 @@ def test_tiles_reassemble_the_whole_image(nl, oracle):
             tl += cl
             th += ch
     assert same_values(out, want) and (tl, th) == (wl, wh)
+    # same with the register-resident sigma kernel: counters add up exactly
+    rc, want, wl, wh, _ = oracle.stack_apply(2, frames, None, 2.5, 2.5)
+    out = np.zeros(width * height, np.float32)
+    tl = th = 0
+    for row0, rows in ((0, 7), (7, 9), (16, 8)):
+        with nl.StackHandle(n, width, height, row0=row0, rows=rows) as st:
+            st.upload_frames(frames)
+            _, cl, ch = st.run(2, 2.5, 2.5, out=out)
+            tl += cl
+            th += ch
+    assert close_values(out, want) and (tl, th) == (wl, wh)
 
 
 def test_synthetic_fill_is_tile_consistent_and_deterministic(nl):
@@ -177,12 +264,15 @@ def test_larger_stack_sigma_and_goal_seek(nl, oracle):
     with nl.StackHandle(n, width, height) as st:
         st.fill_synthetic(99)
         frames = np.stack([st.download_tile(i) for i in range(n)])
-        got, cl, ch = st.run(2, 3.0, 3.0)
         rc, want, wl, wh, _ = oracle.stack_apply(2, frames, None, 3.0, 3.0, num_cpu=8)
-        assert same_values(got, want), describe_mismatch(got, want)
-        assert (cl, ch) == (wl, wh)
-        out, cl, ch, sl, sh, passes = st.find_sigmas(2, 0.5, 0.5)
         op, ores, ocl, och, osl, osh = oracle.find_sigmas_bisect(2, frames, 0.5, 0.5, num_cpu=8)
-        assert (passes, cl, ch) == (op, ocl, och)
-        assert (np.float32(sl), np.float32(sh)) == (osl, osh)
-        assert same_values(out, ores)
+        for exact in (True, False):
+            st.set_exact(exact)
+            got, cl, ch = st.run(2, 3.0, 3.0)
+            assert (cl, ch) == (wl, wh)
+            assert (same_values if exact else close_values)(got, want), describe_mismatch(got, want)
+            # goal-seek takes the same bisection path because the counters are exact
+            out, cl, ch, sl, sh, passes = st.find_sigmas(2, 0.5, 0.5)
+            assert (passes, cl, ch) == (op, ocl, och)
+            assert (np.float32(sl), np.float32(sh)) == (osl, osh)
+            assert (same_values if exact else close_values)(out, ores)

@@ -39,6 +39,9 @@ int fail(int code, const char *fmt, ...)
 
 constexpr int kStatBlocks = 2048;
 constexpr int kListGrid = 2048;     // workgroups of the exact kernel in fallback-list mode
+constexpr int kListLanes = 4;       // pixels per wave there: few pixels, keep divergence low
+// per-pass device scratch, zeroed by one memset: clip accumulators + the two list lengths
+constexpr size_t kScratchBytes = sizeof(unsigned long long) * (2 * nl::kClipSlots + 1);
 
 int next_pow2(int n)
 {
@@ -62,11 +65,10 @@ struct nl_stack {
     float *d_weights = nullptr;       // [n_frames]
     bool has_weights = false;
     float *d_xstat = nullptr;         // [(n_frames+1)*2]
-    unsigned long long *d_partial = nullptr;   // [partial_slots][2]
+    unsigned long long *d_partial = nullptr;   // [kClipSlots][2] clip accumulators + 1 word of list lengths
     unsigned *d_fb_list = nullptr;             // [npix] pixels the fast kernel handed to the exact kernel
-    unsigned *d_fb_count = nullptr;            // [2]: exact-list length, generic-list length
+    unsigned *d_fb_count = nullptr;            // [2]: exact-list length, generic-list length (inside d_partial)
     unsigned *d_gen_list = nullptr;            // [npix] pixels zonal waves handed to the generic pass
-    int partial_slots = 0;
     bool force_exact = false;
     bool last_used_fast = false;
     unsigned long long *d_counters = nullptr;  // [2]
@@ -104,7 +106,6 @@ static int destroy_impl(nl_stack_t *h)
     if (h->d_xstat) (void)hipFree(h->d_xstat);
     if (h->d_partial) (void)hipFree(h->d_partial);
     if (h->d_fb_list) (void)hipFree(h->d_fb_list);
-    if (h->d_fb_count) (void)hipFree(h->d_fb_count);
     if (h->d_gen_list) (void)hipFree(h->d_gen_list);
     if (h->d_counters) (void)hipFree(h->d_counters);
     if (h->d_stat_partial) (void)hipFree(h->d_stat_partial);
@@ -136,14 +137,12 @@ static int create_impl(nl_stack_t *h)
     NL_HIP(hipMalloc(&h->d_out, frame_bytes));
     NL_HIP(hipMalloc(&h->d_weights, sizeof(float) * (size_t)h->n_frames));
     h->max_grid = 256 * 64;
-    const int fast_slots = nl::fast_partial_slots(h->npix);
-    h->partial_slots = (fast_slots > h->max_grid ? fast_slots : h->max_grid) + kListGrid;
-    NL_HIP(hipMalloc(&h->d_partial, sizeof(unsigned long long) * 2 * (size_t)h->partial_slots));
+    NL_HIP(hipMalloc(&h->d_partial, kScratchBytes));
+    NL_HIP(hipMemsetAsync(h->d_partial, 0, kScratchBytes, h->stream));
+    h->d_fb_count = reinterpret_cast<unsigned *>(h->d_partial + 2 * nl::kClipSlots);
     if (h->npix < (int64_t)0xFFFFFFFFll) {
         NL_HIP(hipMalloc(&h->d_fb_list, sizeof(unsigned) * (size_t)h->npix));
         NL_HIP(hipMalloc(&h->d_gen_list, sizeof(unsigned) * (size_t)h->npix));
-        NL_HIP(hipMalloc(&h->d_fb_count, 2 * sizeof(unsigned)));
-        NL_HIP(hipMemsetAsync(h->d_fb_count, 0, 2 * sizeof(unsigned), h->stream));
     }
     NL_HIP(hipMalloc(&h->d_counters, sizeof(unsigned long long) * 2));
     NL_HIP(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * 2, h->stream));
@@ -332,6 +331,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
     a.list_capacity = 0;
 
     NL_HIP(hipEventRecord(h->ev_start, h->stream));
+    NL_HIP(hipMemsetAsync(h->d_partial, 0, kScratchBytes, h->stream));
     if (mode == NL_ST_MEAN) {
         NL_HIP(nl::launch_stack_mean(weighted, a, h->stream, &h->last_kernel));
         h->last_has_counters = false;
@@ -347,22 +347,20 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         f.in_list = nullptr;
         f.in_count = nullptr;
         f.in_capacity = 0;
-        NL_HIP(hipMemsetAsync(h->d_fb_count, 0, 2 * sizeof(unsigned), h->stream));
         int fast_grid = 0;
         NL_HIP(nl::launch_stack_sigma_fast(a, f, &fast_grid, h->stream, &h->last_kernel));
         int lanes = 0;
         size_t lds = 0;
-        if (nl::exact_plan(mode, weighted, a.n_frames, a.n_pad, 16, &lanes, &lds) != 0)
+        if (nl::exact_plan(mode, weighted, a.n_frames, a.n_pad, kListLanes, &lanes, &lds) != 0)
             return fail(NL_ERR_TOO_MANY_FRAMES,
                         "%d frames do not fit the per-pixel LDS column (mode %d)", a.n_frames, mode);
         nl::StackArgs e = a;
         e.list = h->d_fb_list;
         e.list_count = h->d_fb_count;
         e.list_capacity = (unsigned)h->npix;
-        e.partial = h->d_partial + 2 * (size_t)fast_grid;
         const char *exact_name = "";
         NL_HIP(nl::launch_stack_exact(mode, weighted, e, lanes, kListGrid, lds, h->stream, &exact_name));
-        NL_HIP(nl::launch_reduce_counters(h->d_partial, fast_grid + kListGrid, h->d_counters, h->stream));
+        NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
         h->last_has_counters = true;
         h->last_used_fast = true;
     } else {
@@ -375,7 +373,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         a.tiles = (a.npix + lanes - 1) / lanes;
         int grid = (int)(a.tiles < (int64_t)h->max_grid ? a.tiles : (int64_t)h->max_grid);
         NL_HIP(nl::launch_stack_exact(mode, weighted, a, lanes, grid, lds, h->stream, &h->last_kernel));
-        NL_HIP(nl::launch_reduce_counters(h->d_partial, grid, h->d_counters, h->stream));
+        NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
         h->last_has_counters = (mode != NL_ST_MEDIAN);
     }
     NL_HIP(hipEventRecord(h->ev_stop, h->stream));

@@ -369,22 +369,24 @@ __global__ __launch_bounds__(64) void stack_exact_kernel(StackArgs p)
         if (on) p.out[pix] = res;
     }
 
-    // clip totals (stack.go:193-198): wave sum -> one slot per workgroup,
-    // summed by reduce_counters_kernel (deterministic, no atomics)
+    // clip totals (stack.go:193-198): wave sum -> one integer atomic per
+    // workgroup into kClipSlots sharded accumulators (integer adds commute:
+    // the totals are deterministic), summed by reduce_counters_kernel
     const int t_lo = wave_sum(c_lo), t_hi = wave_sum(c_hi);
     if (lane == 0) {
-        p.partial[2 * (size_t)blockIdx.x + 0] = (unsigned long long)t_lo;
-        p.partial[2 * (size_t)blockIdx.x + 1] = (unsigned long long)t_hi;
+        unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+        if (t_lo) atomicAdd(slot + 0, (unsigned long long)t_lo);
+        if (t_hi) atomicAdd(slot + 1, (unsigned long long)t_hi);
     }
 }
 
 __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned long long *partial,
-                                                               int n_blocks,
+                                                               int n_slots,
                                                                unsigned long long *counters)
 {
     __shared__ unsigned long long s_lo[256], s_hi[256];
     unsigned long long lo = 0, hi = 0;
-    for (int i = threadIdx.x; i < n_blocks; i += 256) {
+    for (int i = threadIdx.x; i < n_slots; i += 256) {
         lo += partial[2 * (size_t)i];
         hi += partial[2 * (size_t)i + 1];
     }
@@ -426,7 +428,8 @@ static hipError_t launch_exact_lanes(StackArgs &args, int lanes, int grid, size_
     switch (lanes) {
     case 64: return launch_exact<MODE, W, 64>(args, grid, lds_bytes, stream);
     case 32: return launch_exact<MODE, W, 32>(args, grid, lds_bytes, stream);
-    default: return launch_exact<MODE, W, 16>(args, grid, lds_bytes, stream);
+    case 16: return launch_exact<MODE, W, 16>(args, grid, lds_bytes, stream);
+    default: return launch_exact<MODE, W, 4>(args, grid, lds_bytes, stream);
     }
 }
 
@@ -436,8 +439,8 @@ int exact_plan(int mode, bool weighted, int n_frames, int n_pad, int max_lanes, 
     const int columns = ((mode == NL_ST_MAD_SIGMA) ||
                          (weighted && (mode == NL_ST_SIGMA || mode == NL_ST_WINSOR_SIGMA))) ? 2 : 1;
     const size_t n_alloc = (mode == NL_ST_LINEAR_FIT) ? (size_t)n_pad : (size_t)n_frames;
-    for (int l = 64; l >= 16; l >>= 1) {
-        if (l > max_lanes) continue;
+    for (int l = 64; l >= 4; l >>= 1) {
+        if (l > max_lanes || l == 8) continue;
         const size_t bytes = (size_t)columns * n_alloc * l * sizeof(float);
         if (bytes <= kLdsBudgetBytes) {
             *lanes = l;

@@ -42,6 +42,7 @@ namespace nl {
 constexpr float kU = 5.9604644775390625e-8f;   // 2^-24, fp32 unit roundoff
 constexpr int kZone = 8;      // sorted positions per side that may be clipped in the zonal path
 constexpr int kPadMax = 8;    // missing samples (NaN) a lane may have in the zonal path
+constexpr unsigned kGenericGrid = 2048;   // workgroups of the generic pass over the hand-over list
 
 // compile-time loops: every index is a constant, so register columns never
 // fall back to scratch memory (pragma unroll gives up on the large networks)
@@ -158,19 +159,23 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
     static_assert(!ZONAL || NS >= 48, "zonal passes need room between the zones");
     constexpr int ZL = kZone;                                 // low zone  = positions [0, ZL)
     constexpr int ZH = ZONAL ? NS - kZone - kPadMax : NS;     // high zone = positions [ZH, NS)
-    const int N = p.n_frames;
 
     int c_lo_total = 0, c_hi_total = 0;
-    // one item per lane, no loop (a loop would let the compiler hoist the 128
-    // per-frame scalar address selects out of it and spill them).  ZONAL, or
-    // GENERIC without a list: item = tile pixel; GENERIC with a list: item =
-    // position in the hand-over list (workgroups beyond its length exit).
-    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // ZONAL, or GENERIC without a list: the grid covers the tile, one pixel per
+    // lane, a single trip.  GENERIC with a list: grid-stride over the hand-over
+    // list, whose length is only known on the device.
     const bool listed = !ZONAL && q.in_list != nullptr;
     const int64_t limit = listed ? (int64_t)min(*q.in_count, q.in_capacity) : p.npix;
-    const bool wg_has_work = (int64_t)blockIdx.x * blockDim.x < limit;
+    const int64_t sweep = listed ? (int64_t)gridDim.x * blockDim.x : limit;
+    const int lane = threadIdx.x & 63;
 
-    if (wg_has_work) {
+    for (int64_t wg_item = (int64_t)blockIdx.x * blockDim.x; wg_item < limit; wg_item += sweep) {
+        // the frame count is re-read through an opaque register every trip:
+        // otherwise the compiler hoists the 128 per-frame scalar selects that
+        // depend on it out of the loop and spills them
+        int N = p.n_frames;
+        asm volatile("" : "+s"(N));
+        const int64_t item = wg_item + threadIdx.x;
         const bool on = item < limit;
         int64_t pix = item;
         if (listed) pix = on ? (int64_t)q.in_list[item] : 0;
@@ -190,120 +195,118 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
             });
         }
         // NaN = no data (stack.go:380-387): NaNs and unused positions become
-        // +Inf and sort last; a genuine +-Inf sample sends the pixel to the
-        // exact kernel
-        int nan_cnt = 0, nonfinite_cnt = 0;
+        // +Inf and sort last.  A genuine +-Inf sample stays among the n valid
+        // ones, makes the variance non-finite and thereby sends the pixel to
+        // the exact kernel (the `bail` test below).
+        int nan_cnt = 0;
         static_chunks<0, NS, 16>([&](auto K) NL_INL {
             constexpr int k = decltype(K)::value;
             float x = v[k];
             x = (k < N) ? x : __builtin_nanf("");
             nan_cnt += (x != x) ? 1 : 0;
-            nonfinite_cnt += !(fabsf(x) < __builtin_inff()) ? 1 : 0;
             v[k] = fminf(x, __builtin_inff());          // minnum(NaN, Inf) = Inf
         });
         const int n = NS - nan_cnt;
-        bool to_exact = nonfinite_cnt != nan_cnt;
+        bool to_exact = false;
         sort_network<NS>(v);
 
         float res = p.ref_loc;
         int c_lo = 0, c_hi = 0;
         int a = 0, b = n;                       // surviving samples = sorted positions [a, b)
-        bool active = on && n > 0 && !to_exact;
+        bool active = on && n > 0;
         bool to_generic = false;
         if constexpr (ZONAL) {
-            // zonal passes need b > ZH (and a < ZL) for every active lane
-            if (!__all(!active || (n > ZH))) {
-                to_generic = active;
-                active = false;
-            }
+            // zonal passes need b > ZH (and a < ZL): lanes with more missing
+            // samples are handed to the generic pass, the others carry on
+            to_generic = active && !(n > ZH);
+            active = active && !to_generic;
+        }
+
+        // Shift c = first-pass median (any value near the bulk works).  With
+        // D = sum(x-c) and Q = sum((x-c)^2) over the survivors,
+        //     mean = c + D/cnt,   var = Q/cnt - (mean-c)^2        (exact identities).
+        // Positions [ZL,ZH) are never clipped in the zonal passes, so their
+        // share of D and Q is computed once; an iteration only re-sums the zones.
+        constexpr int W0 = ZONAL ? ZH / 2 - 1 : 0, W1 = ZONAL ? ZL + NS / 2 + 1 : NS;
+        const float c = pick<W0, W1>(v, a + ((b - a) >> 1));
+        float d_mid = 0.0f, q_mid = 0.0f;
+        if constexpr (ZONAL) {
+            float d0 = 0, d1 = 0, d2 = 0, d3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+            static_chunks<0, (ZH - ZL) / 4, 4>([&](auto K) NL_INL {
+                constexpr int k = ZL + 4 * decltype(K)::value;
+                const float e0 = v[k] - c, e1 = v[k + 1] - c, e2 = v[k + 2] - c, e3 = v[k + 3] - c;
+                d0 += e0; d1 += e1; d2 += e2; d3 += e3;
+                q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
+                q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
+            });
+            d_mid = (d0 + d1) + (d2 + d3);
+            q_mid = (q0 + q1) + (q2 + q3);
         }
 
         while (__any(active)) {
             const int cnt = b - a;
             const float fcnt = (float)cnt;
-            float m, var, amax;
+            float dz0 = 0.0f, dz1 = 0.0f, qz0 = 0.0f, qz1 = 0.0f, amax;
             if constexpr (ZONAL) {
-                // ---- mean~: unmasked middle, masked zones ----
-                float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
                 static_range<0, ZL>([&](auto K) NL_INL {
                     constexpr int k = decltype(K)::value;
-                    s0 += (k >= a) ? v[k] : 0.0f;
-                });
-                static_chunks<0, (ZH - ZL) / 4, 8>([&](auto K) NL_INL {
-                    constexpr int k = ZL + 4 * decltype(K)::value;
-                    s0 += v[k]; s1 += v[k + 1]; s2 += v[k + 2]; s3 += v[k + 3];
+                    const float e = (k >= a) ? v[k] - c : 0.0f;
+                    dz0 += e;
+                    qz0 = __builtin_fmaf(e, e, qz0);
                 });
                 static_range<ZH, NS>([&](auto K) NL_INL {
                     constexpr int k = decltype(K)::value;
-                    s1 += (k < b) ? v[k] : 0.0f;
+                    const float e = (k < b) ? v[k] - c : 0.0f;
+                    dz1 += e;
+                    qz1 = __builtin_fmaf(e, e, qz1);
                 });
-                m = ((s0 + s1) + (s2 + s3)) / fcnt;
-                float q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-                static_range<0, ZL>([&](auto K) NL_INL {
-                    constexpr int k = decltype(K)::value;
-                    const float d = (k >= a) ? v[k] - m : 0.0f;
-                    q0 = __builtin_fmaf(d, d, q0);
-                });
-                static_chunks<0, (ZH - ZL) / 4, 4>([&](auto K) NL_INL {
-                    constexpr int k = ZL + 4 * decltype(K)::value;
-                    const float d0 = v[k] - m, d1 = v[k + 1] - m, d2 = v[k + 2] - m, d3 = v[k + 3] - m;
-                    q0 = __builtin_fmaf(d0, d0, q0); q1 = __builtin_fmaf(d1, d1, q1);
-                    q2 = __builtin_fmaf(d2, d2, q2); q3 = __builtin_fmaf(d3, d3, q3);
-                });
-                static_range<ZH, NS>([&](auto K) NL_INL {
-                    constexpr int k = decltype(K)::value;
-                    const float d = (k < b) ? v[k] - m : 0.0f;
-                    q1 = __builtin_fmaf(d, d, q1);
-                });
-                var = ((q0 + q1) + (q2 + q3)) / fcnt;
                 // sorted: max|x| of the survivors is at one of the two ends
                 amax = fmaxf(fabsf(pick<0, ZL>(v, a)), fabsf(pick<ZH, NS>(v, b - 1)));
             } else {
                 const int a1 = opaque(a);
-                float s0 = 0, s1 = 0, s2 = 0, s3 = 0, sa = 0;
+                float sa = 0.0f, dz2 = 0.0f, dz3 = 0.0f, qz2 = 0.0f, qz3 = 0.0f;
                 static_chunks<0, NS / 4, 2>([&](auto K) NL_INL {
                     constexpr int k = 4 * decltype(K)::value;
-                    const float x0 = ((unsigned)(k + 0 - a1) < (unsigned)cnt) ? v[k + 0] : 0.0f;
-                    const float x1 = ((unsigned)(k + 1 - a1) < (unsigned)cnt) ? v[k + 1] : 0.0f;
-                    const float x2 = ((unsigned)(k + 2 - a1) < (unsigned)cnt) ? v[k + 2] : 0.0f;
-                    const float x3 = ((unsigned)(k + 3 - a1) < (unsigned)cnt) ? v[k + 3] : 0.0f;
-                    s0 += x0; s1 += x1; s2 += x2; s3 += x3;
-                    sa = fmaxf(fmaxf(sa, fabsf(x0)), fabsf(x1));
-                    sa = fmaxf(fmaxf(sa, fabsf(x2)), fabsf(x3));
+                    const bool i0 = (unsigned)(k + 0 - a1) < (unsigned)cnt;
+                    const bool i1 = (unsigned)(k + 1 - a1) < (unsigned)cnt;
+                    const bool i2 = (unsigned)(k + 2 - a1) < (unsigned)cnt;
+                    const bool i3 = (unsigned)(k + 3 - a1) < (unsigned)cnt;
+                    const float e0 = i0 ? v[k + 0] - c : 0.0f, e1 = i1 ? v[k + 1] - c : 0.0f;
+                    const float e2 = i2 ? v[k + 2] - c : 0.0f, e3 = i3 ? v[k + 3] - c : 0.0f;
+                    dz0 += e0; dz1 += e1; dz2 += e2; dz3 += e3;
+                    qz0 = __builtin_fmaf(e0, e0, qz0); qz1 = __builtin_fmaf(e1, e1, qz1);
+                    qz2 = __builtin_fmaf(e2, e2, qz2); qz3 = __builtin_fmaf(e3, e3, qz3);
+                    sa = fmaxf(fmaxf(sa, i0 ? fabsf(v[k + 0]) : 0.0f), i1 ? fabsf(v[k + 1]) : 0.0f);
+                    sa = fmaxf(fmaxf(sa, i2 ? fabsf(v[k + 2]) : 0.0f), i3 ? fabsf(v[k + 3]) : 0.0f);
                 });
-                m = ((s0 + s1) + (s2 + s3)) / fcnt;
+                dz0 += dz2; dz1 += dz3; qz0 += qz2; qz1 += qz3;
                 amax = sa;
-                const int a2 = opaque(a);
-                float q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-                static_chunks<0, NS / 4, 2>([&](auto K) NL_INL {
-                    constexpr int k = 4 * decltype(K)::value;
-                    const float d0 = ((unsigned)(k + 0 - a2) < (unsigned)cnt) ? v[k + 0] - m : 0.0f;
-                    const float d1 = ((unsigned)(k + 1 - a2) < (unsigned)cnt) ? v[k + 1] - m : 0.0f;
-                    const float d2 = ((unsigned)(k + 2 - a2) < (unsigned)cnt) ? v[k + 2] - m : 0.0f;
-                    const float d3 = ((unsigned)(k + 3 - a2) < (unsigned)cnt) ? v[k + 3] - m : 0.0f;
-                    q0 = __builtin_fmaf(d0, d0, q0); q1 = __builtin_fmaf(d1, d1, q1);
-                    q2 = __builtin_fmaf(d2, d2, q2); q3 = __builtin_fmaf(d3, d3, q3);
-                });
-                var = ((q0 + q1) + (q2 + q3)) / fcnt;
             }
+            const float dsum = d_mid + (dz0 + dz1);
+            const float qsum = q_mid + (qz0 + qz1);
+            const float delta = dsum / fcnt;             // mean~ - c
+            const float m = c + delta;
+            const float aa = qsum / fcnt;                // E[(x-c)^2]~
+            const float bb = delta * delta;
+            const float var = fmaxf(aa - bb, 0.0f);
 
             // ---- bracket the reference's stddev ----
-            // relative slack on the variance: reference gamma_(n+3), ours, margins
-            const float eps = (fcnt + 64.0f) * kU;
-            // |reference mean - true mean| <= gamma_n * mean|x| <= e_m
+            // ours: every term of aa and bb carries <= ~(NS/4+16) roundings
+            const float err_o = ((float)(NS / 4 + 24)) * kU * (aa + bb);
+            // reference: relative gamma_(n+3) on its variance, its mean off by <= e_m
+            const float eps_r = 1.02f * (fcnt + 8.0f) * kU;
             const float e_m = 1.02f * (fcnt + 2.0f) * kU * amax;
-            // |our mean - true mean| <= gamma_(NS/4+24) * mean|x| <= e_o
-            const float e_o = 1.02f * ((float)(NS / 4 + 24)) * kU * amax;
-            const float v_hi = var + var * eps + e_m * e_m;
-            const float v_lo = fmaxf(var - var * eps - e_o * e_o, 0.0f);
+            const float v_up = var + err_o;
+            const float v_dn = fmaxf(var - err_o, 0.0f);
+            const float v_hi = v_up + v_up * eps_r + e_m * e_m;
+            const float v_lo = fmaxf(v_dn - v_dn * eps_r, 0.0f);
             const float s_max = __fsqrt_rn(v_hi) * (1.0f + 4.0f * kU);
             const float s_min = __fsqrt_rn(v_lo) * (1.0f - 4.0f * kU);
-            bool bail = !(v_hi < 3.0e38f);          // overflow / NaN: exact kernel
+            bool bail = !(v_hi < 3.0e38f);          // overflow / NaN (e.g. an Inf sample): exact kernel
 
             // ---- exact median (qsort.go:68-82): sorted column, position lookup ----
-            const int kk = a + (cnt >> 1);
             // zonal: a in [0,ZL), b in (ZH,NS]  =>  kk in [ZH/2, ZL-1+NS/2]
-            constexpr int W0 = ZONAL ? ZH / 2 - 1 : 0, W1 = ZONAL ? ZL + NS / 2 + 1 : NS;
+            const int kk = a + (cnt >> 1);
             const float upper = pick<W0, W1>(v, kk);
             const float lower = pick<W0, W1>(v, kk - 1);
             const float median = (cnt & 1) ? upper : 0.5f * (lower + upper);
@@ -334,10 +337,9 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                 });
                 // the zones must still hold a survivor on each side, otherwise the
                 // next sorted position (outside the zone) might be clipped as well:
-                // the whole wave restarts these pixels in the generic kernel
-                const bool overflow = active && ((a + c2 >= ZL) || (b - d2 <= ZH));
-                if (__any(overflow)) {
-                    to_generic = active;
+                // such a lane restarts in the generic pass
+                if (active && ((a + c2 >= ZL) || (b - d2 <= ZH))) {
+                    to_generic = true;
                     active = false;
                 }
             } else {
@@ -372,18 +374,30 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
             }
         }
 
-        if (on) {
-            if (to_generic) {
-                const unsigned slot = atomicAdd(q.gen_count, 1u);
-                if (slot < q.gen_capacity) q.gen_list[slot] = (unsigned)pix;
-            } else if (to_exact) {
-                const unsigned slot = atomicAdd(q.fb_count, 1u);
-                if (slot < q.fb_capacity) q.fb_list[slot] = (unsigned)pix;
-            } else {
-                p.out[pix] = res;
-                c_lo_total += c_lo;
-                c_hi_total += c_hi;
+        if (on && !to_generic && !to_exact) {
+            p.out[pix] = res;
+            c_lo_total += c_lo;
+            c_hi_total += c_hi;
+        }
+        // hand-over lists: one atomic per wave reserves a contiguous run, lanes
+        // fill it in lane order, so the consumer's loads stay coalesced
+        if constexpr (ZONAL) {
+            const unsigned long long gm = __ballot(on && to_generic);
+            if (gm) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(q.gen_count, (unsigned)__popcll(gm));
+                base = __shfl(base, 0, 64);
+                const unsigned slot = base + (unsigned)__popcll(gm & ((1ull << lane) - 1ull));
+                if (on && to_generic && slot < q.gen_capacity) q.gen_list[slot] = (unsigned)pix;
             }
+        }
+        const unsigned long long em = __ballot(on && to_exact);
+        if (em) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(q.fb_count, (unsigned)__popcll(em));
+            base = __shfl(base, 0, 64);
+            const unsigned slot = base + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
+            if (on && to_exact && slot < q.fb_capacity) q.fb_list[slot] = (unsigned)pix;
         }
     }
 
@@ -397,8 +411,11 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
     if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = c_lo_total; s_hi[threadIdx.x >> 6] = c_hi_total; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        p.partial[2 * (size_t)blockIdx.x + 0] = (unsigned long long)(s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3]);
-        p.partial[2 * (size_t)blockIdx.x + 1] = (unsigned long long)(s_hi[0] + s_hi[1] + s_hi[2] + s_hi[3]);
+        const int t_lo = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3];
+        const int t_hi = s_hi[0] + s_hi[1] + s_hi[2] + s_hi[3];
+        unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+        if (t_lo) atomicAdd(slot + 0, (unsigned long long)t_lo);
+        if (t_hi) atomicAdd(slot + 1, (unsigned long long)t_hi);
     }
 }
 
@@ -419,24 +436,21 @@ static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned t
     if constexpr (NS >= 48) {
         hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true>), dim3(tile_blocks), dim3(256), 0,
                            stream, args, f);
-        // generic pass over the pixels the zonal waves handed over
-        StackArgs g = args;
-        g.partial = args.partial + 2 * (size_t)tile_blocks;
+        // generic pass over the pixels the zonal waves handed over (its length
+        // is only known on the device: fixed grid, grid-stride loop)
         f.in_list = fargs.gen_list;
         f.in_count = fargs.gen_count;
         f.in_capacity = fargs.gen_capacity;
-        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false>), dim3(tile_blocks), dim3(256), 0,
-                           stream, g, f);
-        *blocks_used = 2 * (int)tile_blocks;
+        const unsigned gblocks = tile_blocks < kGenericGrid ? tile_blocks : kGenericGrid;
+        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false>), dim3(gblocks), dim3(256), 0,
+                           stream, args, f);
     } else {
         // small stacks: generic passes are cheap, run them over the whole tile
         hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false>), dim3(tile_blocks), dim3(256), 0,
                            stream, args, f);
-        *blocks_used = (int)tile_blocks;
     }
+    *blocks_used = 0;
 }
-
-int fast_partial_slots(int64_t npix) { return 2 * (int)((npix + 255) / 256); }
 
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, int *blocks_used,
                                    hipStream_t stream, const char **name)

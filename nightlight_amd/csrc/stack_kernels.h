@@ -10,6 +10,8 @@ namespace nl {
 
 // 160 KiB LDS per CU (MI355X); a single workgroup may use all of it.
 constexpr size_t kLdsBudgetBytes = 160 * 1024;
+// clip counters: sharded accumulators [kClipSlots][2], zeroed before every pass
+constexpr int kClipSlots = 256;
 
 struct StackArgs {
     const float *frames;          // planar [n_frames][stride] fp32
@@ -22,7 +24,7 @@ struct StackArgs {
     const float *xstat;           // device, [n_frames+1][2]: MeanStdDev of 0..n-1 (linear fit)
     float sig_lo, sig_hi, ref_loc;
     float *out;                   // [npix]
-    unsigned long long *partial;  // [grid][2] clip counters per workgroup
+    unsigned long long *partial;  // [kClipSlots][2] sharded clip counters (atomic adds)
     const unsigned *list;         // optional: pixel indices to process instead of 0..npix-1
     const unsigned *list_count;   // device-side length of `list`
     unsigned list_capacity;
@@ -52,7 +54,6 @@ hipError_t launch_reduce_counters(const unsigned long long *partial, int n_block
 
 // ---- stack_fast.hip ----
 int fast_supported(int mode, bool weighted, int n_frames);
-int fast_partial_slots(int64_t npix);
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, int *blocks_used,
                                    hipStream_t stream, const char **name);
 

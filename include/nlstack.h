@@ -171,6 +171,21 @@ int nl_stack_weights_from_noise(nl_stack_t *h, float *noise_out);
  * host in/out, width*height floats each; border rows/columns copied. */
 int nl_median_filter_3x3(const float *in_host, float *out_host, int width, int height, int device);
 
+/* ---- host-side operator mirror (nightlight_amd/host/, C++) ----
+ * The reference's stack operator decoded from its JSON form and run through
+ * MakePromises/Apply exactly as OpSequence would drive it
+ * (internal/ops/operator.go:484-513, internal/ops/stack/stack.go:92-227), on
+ * host frames (frames[i] == NULL is a frame skipped upstream, "(nil, nil)").
+ * Returns 0 on success; on failure err_buf holds the reference's message.
+ * log_buf receives what the operator wrote to Context.Log. */
+int nl_host_op_stack_apply_json(const char *json, int n_frames, int width, int height,
+                                const float *const *frames, const float *exposure,
+                                const float *hfr, int device, int max_threads,
+                                float *out, float *exposure_out,
+                                char *log_buf, int log_cap, char *err_buf, int err_cap);
+/* Unmarshal with defaults (stack.go:92-99), marshal back. */
+const char *nl_host_op_stack_roundtrip_json(const char *json);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,7 @@ EXPORTS = [
     "nl_stack_find_sigmas", "nl_stack_accumulate", "nl_stack_accumulate_finalize",
     "nl_stack_frame_stats", "nl_stack_frame_noise", "nl_stack_weights_from_noise",
     "nl_median_filter_3x3",
+    "nl_host_op_stack_apply_json", "nl_host_op_stack_roundtrip_json",
 ]
 
 
@@ -108,6 +109,11 @@ def load():
     L.nl_stack_frame_noise.argtypes = [vp, C.c_int, _f32p]
     L.nl_stack_weights_from_noise.argtypes = [vp, _f32p]
     L.nl_median_filter_3x3.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int]
+    L.nl_host_op_stack_apply_json.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                              C.POINTER(_f32p), _f32p, _f32p, C.c_int, C.c_int,
+                                              _f32p, _f32p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    L.nl_host_op_stack_roundtrip_json.argtypes = [C.c_char_p]
+    L.nl_host_op_stack_roundtrip_json.restype = C.c_char_p
     _lib = L
     return L
 

@@ -1,0 +1,362 @@
+// op_stack.cpp -- host-side mirror of the reference's operator runtime and its
+// "stack" operator on top of the C ABI (include/nlstack.h).  Restates the
+// bookkeeping of internal/ops/operator.go:73-166 and
+// internal/ops/stack/stack.go:75-270; no pixel arithmetic happens here.
+#include "op_stack.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <sstream>
+#include <stdexcept>
+#include <thread>
+
+#include "../../include/nlstack.h"
+
+namespace nightlight {
+
+// ---- internal/fits/fits.go:66-90 -------------------------------------------
+ImagePtr NewImageFromNaxisn(const std::vector<int32_t> &naxisn, std::vector<float> data)
+{
+    int32_t pixels = 1;
+    for (int32_t n : naxisn) pixels *= n;
+    auto img = std::make_shared<Image>();
+    img->Naxisn = naxisn;
+    img->Pixels = pixels;
+    if (data.empty()) data.assign((size_t)pixels, 0.0f);
+    img->Data = std::move(data);
+    return img;
+}
+
+// ---- internal/ops/operator.go:119-131 ----------------------------------------
+std::vector<ImagePtr> RemoveNils(std::vector<ImagePtr> lights)
+{
+    lights.erase(std::remove(lights.begin(), lights.end(), nullptr), lights.end());
+    return lights;
+}
+
+// ---- internal/ops/operator.go:73-116 ------------------------------------------
+std::vector<ImagePtr> MaterializeAll(const std::vector<Promise> &ins, int maxThreads, bool forget,
+                                     std::string *err)
+{
+    if (err) err->clear();
+    if (ins.empty()) return {};
+    if (maxThreads < 1) maxThreads = 1;
+    std::vector<ImagePtr> outs(forget ? 0 : ins.size());
+    std::vector<std::string> errs(ins.size());
+    std::mutex mu;
+    std::condition_variable cv;
+    int running = 0;
+    std::vector<std::thread> threads;
+    threads.reserve(ins.size());
+    for (size_t i = 0; i < ins.size(); i++) {
+        {
+            std::unique_lock<std::mutex> lk(mu);       // the buffered-channel limiter
+            cv.wait(lk, [&] { return running < maxThreads; });
+            running++;
+        }
+        threads.emplace_back([&, i] {
+            Result r = ins[i]();
+            if (!r.err.empty()) errs[i] = r.err;
+            else if (!forget) outs[i] = r.image;
+            std::lock_guard<std::mutex> lk(mu);
+            running--;
+            cv.notify_one();
+        });
+    }
+    for (auto &t : threads) t.join();
+    std::string all;                                   // distinct messages joined with "; "
+    for (const auto &e : errs) {
+        if (e.empty()) continue;
+        if (all.empty()) all = e;
+        else if (all == e) continue;
+        else all = all + "; " + e;
+    }
+    if (err) *err = all;
+    return RemoveNils(std::move(outs));
+}
+
+// ---- internal/ops/operator.go:147-166 -----------------------------------------
+static std::map<std::string, OperatorFactory> &factories()
+{
+    static std::map<std::string, OperatorFactory> m;
+    return m;
+}
+
+OperatorFactory GetOperatorFactory(const std::string &type)
+{
+    auto it = factories().find(type);
+    return it == factories().end() ? OperatorFactory() : it->second;
+}
+
+void SetOperatorFactory(OperatorFactory f)
+{
+    const std::string t = f()->GetType();
+    if (GetOperatorFactory(t)) throw std::logic_error("error: re-registering operator key " + t + "\n");
+    factories()[t] = std::move(f);
+}
+
+// ---- internal/ops/stack/stack.go:75-99 -------------------------------------------
+std::shared_ptr<OpStack> NewOpStack(int mode, int weighting, float sigmaLow, float sigmaHigh)
+{
+    auto op = std::make_shared<OpStack>();
+    op->Type = "stack";
+    op->Mode = mode;
+    op->Weighting = weighting;
+    op->SigmaLow = sigmaLow;
+    op->SigmaHigh = sigmaHigh;
+    op->RefFrameLoc = 0;
+    return op;
+}
+
+std::shared_ptr<OpStack> NewOpStackDefault() { return NewOpStack(StAuto, StWeightNone, 2.75f, 2.75f); }
+
+void RegisterOpStack()
+{
+    if (!GetOperatorFactory("stack"))
+        SetOperatorFactory([]() -> std::shared_ptr<Operator> { return NewOpStackDefault(); });
+}
+
+static std::string fmt_g(float v)
+{
+    char buf[64];
+    snprintf(buf, sizeof buf, "%g", (double)v);      // Go's %g prints the shortest form too
+    return buf;
+}
+
+std::string OpStack::MarshalJSON() const
+{
+    std::ostringstream o;
+    o << "{\"type\":\"" << Type << "\",\"mode\":" << Mode << ",\"weighting\":" << Weighting
+      << ",\"sigmaLow\":" << fmt_g(SigmaLow) << ",\"sigmaHigh\":" << fmt_g(SigmaHigh) << "}";
+    return o.str();
+}
+
+// flat JSON object with number / string values -- all the stack operator has
+static bool find_value(const std::string &s, const std::string &key, std::string *out)
+{
+    const std::string pat = "\"" + key + "\"";
+    size_t p = s.find(pat);
+    if (p == std::string::npos) return false;
+    p = s.find(':', p + pat.size());
+    if (p == std::string::npos) return false;
+    p++;
+    while (p < s.size() && isspace((unsigned char)s[p])) p++;
+    size_t e = p;
+    if (p < s.size() && s[p] == '"') {
+        e = s.find('"', p + 1);
+        if (e == std::string::npos) return false;
+        *out = s.substr(p + 1, e - p - 1);
+        return true;
+    }
+    while (e < s.size() && s[e] != ',' && s[e] != '}' && !isspace((unsigned char)s[e])) e++;
+    *out = s.substr(p, e - p);
+    return !out->empty();
+}
+
+bool OpStack::UnmarshalJSON(const std::string &data, std::string *err)
+{
+    OpStack def = *NewOpStackDefault();
+    std::string v;
+    size_t open = data.find('{'), close = data.rfind('}');
+    if (open == std::string::npos || close == std::string::npos || close < open) {
+        if (err) *err = "invalid character in JSON for operator stack";
+        return false;
+    }
+    char *end = nullptr;
+    if (find_value(data, "type", &v)) def.Type = v;
+    if (find_value(data, "mode", &v)) def.Mode = (int)strtol(v.c_str(), &end, 10);
+    if (find_value(data, "weighting", &v)) def.Weighting = (int)strtol(v.c_str(), &end, 10);
+    if (find_value(data, "sigmaLow", &v)) def.SigmaLow = strtof(v.c_str(), &end);
+    if (find_value(data, "sigmaHigh", &v)) def.SigmaHigh = strtof(v.c_str(), &end);
+    Type = def.Type; Mode = def.Mode; Weighting = def.Weighting;
+    SigmaLow = def.SigmaLow; SigmaHigh = def.SigmaHigh; RefFrameLoc = 0;
+    return true;
+}
+
+// ---- stack.go:102-111 ----------------------------------------------------------------
+std::vector<Promise> OpStack::MakePromises(const std::vector<Promise> &ins, Context *c, std::string *err)
+{
+    if (ins.empty()) {
+        if (err) *err = Type + " operator needs inputs";
+        return {};
+    }
+    if (err) err->clear();
+    auto self = this;
+    Promise out = [self, ins, c]() -> Result {
+        std::string e;
+        std::vector<ImagePtr> fs = MaterializeAll(ins, c->MaxThreads, false, &e);
+        if (!e.empty()) return {nullptr, e};
+        return self->Apply(fs, c);
+    };
+    return {out};
+}
+
+// ---- stack.go:231-270 ------------------------------------------------------------------
+std::vector<float> getWeights(const std::vector<ImagePtr> &f, int weighting, std::string *err)
+{
+    if (err) err->clear();
+    std::vector<float> per(f.size()), w(f.size());
+    if (weighting == StWeightNone) return {};
+    if (weighting == StWeightExposure) {
+        for (size_t i = 0; i < f.size(); i++) per[i] = f[i]->Exposure;
+    } else if (weighting == StWeightInverseNoise) {
+        for (size_t i = 0; i < f.size(); i++) {
+            if (!f[i]->Stats) {
+                if (err) *err = std::to_string(f[i]->ID) + ": Missing stats information for noise-weighted stacking";
+                return {};
+            }
+            per[i] = f[i]->Stats->Noise();
+        }
+    } else if (weighting == StWeightInverseHFR) {
+        for (size_t i = 0; i < f.size(); i++) per[i] = f[i]->HFR;
+    }
+    int bad = -1;
+    int rc = nl_weights_from_scalars(weighting, per.data(), (int)per.size(), w.data(), &bad);
+    if (rc == NL_ERR_MISSING_EXPOSURE) {
+        if (err) *err = std::to_string(f[(size_t)bad]->ID) + ": Missing exposure information for exposure-weighted stacking";
+        return {};
+    }
+    if (rc != NL_OK) {
+        if (err) *err = nl_last_error();
+        return {};
+    }
+    return w;
+}
+
+static int autoSelectStackingMode(int l)   // stack.go:45-55
+{
+    if (l >= 25) return StLinearFit;
+    if (l >= 15) return StWinsorSigma;
+    if (l >= 6) return StSigma;
+    return StMean;
+}
+
+// ---- stack.go:115-227 ------------------------------------------------------------------
+Result OpStack::Apply(const std::vector<ImagePtr> &f, Context *c)
+{
+    int mode = Mode;
+    if (mode < StMedian || mode > StAuto) return {nullptr, "invalid stacking mode"};
+    if (f.empty()) return {nullptr, Type + " operator needs inputs"};
+    if (mode == StAuto) mode = autoSelectStackingMode((int)f.size());
+    if (c && c->Log) {
+        char line[256];
+        snprintf(line, sizeof line, "Stacking %d frames with stacking mode %d and sigma low %g high %g:\n",
+                 (int)f.size(), mode, (double)SigmaLow, (double)SigmaHigh);
+        *c->Log << line;
+    }
+
+    std::string err;
+    std::vector<float> weights = getWeights(f, Weighting, &err);
+    if (!err.empty()) return {nullptr, err};
+    if (Weighting != StWeightNone && weights.empty() && Weighting > StWeightInverseHFR) {
+        char msg[64];
+        snprintf(msg, sizeof msg, "Invalid weighting mode %d\n", Weighting);
+        return {nullptr, msg};
+    }
+
+    const std::vector<int32_t> &naxisn = f[0]->Naxisn;
+    const int width = naxisn.empty() ? (int)f[0]->Data.size() : naxisn[0];
+    const int height = width > 0 ? (int)(f[0]->Data.size() / (size_t)width) : 0;
+    nl_stack_t *h = nl_stack_create((int)f.size(), width, height, 0, height, c ? c->Device : 0);
+    if (!h) return {nullptr, nl_last_error()};
+    Result out;
+    do {
+        int rc = NL_OK;
+        for (size_t i = 0; i < f.size() && rc == NL_OK; i++) {
+            if (f[i]->Data.size() != f[0]->Data.size()) { out.err = "frames differ in size"; break; }
+            rc = nl_stack_upload_frame(h, (int)i, f[i]->Data.data());
+        }
+        if (!out.err.empty()) break;
+        if (rc == NL_OK) rc = nl_stack_set_weights(h, weights.empty() ? nullptr : weights.data());
+        std::vector<float> data(f[0]->Data.size());
+        int64_t clipLow = 0, clipHigh = 0;
+        if (rc == NL_OK) rc = nl_stack_run(h, mode, SigmaLow, SigmaHigh, RefFrameLoc, data.data(), &clipLow, &clipHigh);
+        if (rc != NL_OK) { out.err = nl_last_error(); break; }
+        if (mode >= StSigma && c && c->Log) {          // stack.go:214-218
+            const float total = (float)((int64_t)data.size() * (int64_t)f.size());
+            char line[256];
+            snprintf(line, sizeof line, "Clipped low %lld (%.2f%%) high %lld (%.2f%%)\n",
+                     (long long)clipLow, (double)((float)clipLow * 100.0f / total),
+                     (long long)clipHigh, (double)((float)clipHigh * 100.0f / total));
+            *c->Log << line;
+        }
+        float exposureSum = 0;
+        for (const auto &l : f) exposureSum += l->Exposure;
+        out.image = NewImageFromNaxisn(naxisn, std::move(data));
+        out.image->Exposure = exposureSum;
+    } while (false);
+    nl_stack_destroy(h);
+    return out;
+}
+
+}  // namespace nightlight
+
+// ---- plain-C entry used by the tests (and by other hosts that only have
+// host buffers): decode the operator from JSON exactly as OpSequence would
+// (operator.go:484-513: factory lookup by "type", then UnmarshalJSON), run it
+// through MakePromises on frames supplied as promises.
+extern "C" int nl_host_op_stack_apply_json(const char *json, int n_frames, int width, int height,
+                                           const float *const *frames, const float *exposure,
+                                           const float *hfr, int device, int max_threads,
+                                           float *out, float *exposure_out,
+                                           char *log_buf, int log_cap, char *err_buf, int err_cap)
+{
+    using namespace nightlight;
+    auto put = [](char *dst, int cap, const std::string &s) {
+        if (dst && cap > 0) { snprintf(dst, (size_t)cap, "%s", s.c_str()); }
+    };
+    put(err_buf, err_cap, "");
+    put(log_buf, log_cap, "");
+    RegisterOpStack();
+    std::string type, err;
+    const std::string js = json ? json : "{}";
+    if (!find_value(js, "type", &type)) type = "stack";
+    OperatorFactory fac = GetOperatorFactory(type);
+    if (!fac) { put(err_buf, err_cap, "Unknown operator type '" + type + "'"); return 1; }
+    std::shared_ptr<Operator> op = fac();
+    auto *st = dynamic_cast<OpStack *>(op.get());
+    if (!st || !st->UnmarshalJSON(js, &err)) { put(err_buf, err_cap, err); return 1; }
+
+    std::ostringstream log;
+    Context ctx;
+    ctx.Log = &log;
+    ctx.MaxThreads = max_threads > 0 ? max_threads : 1;
+    ctx.Device = device;
+    std::vector<Promise> ins;
+    for (int i = 0; i < n_frames; i++) {
+        ins.push_back([=]() -> Result {
+            if (!frames[i]) return {nullptr, ""};          // (nil, nil): frame skipped upstream
+            std::vector<float> d(frames[i], frames[i] + (size_t)width * height);
+            ImagePtr img = NewImageFromNaxisn({width, height}, std::move(d));
+            img->ID = i;
+            img->Exposure = exposure ? exposure[i] : 0.0f;
+            img->HFR = hfr ? hfr[i] : 0.0f;
+            return {img, ""};
+        });
+    }
+    std::vector<Promise> outs = op->MakePromises(ins, &ctx, &err);
+    if (!err.empty()) { put(err_buf, err_cap, err); return 1; }
+    if (outs.size() != 1) { put(err_buf, err_cap, "stacking returned more than one promise"); return 1; }
+    Result r = outs[0]();
+    put(log_buf, log_cap, log.str());
+    if (!r.err.empty() || !r.image) { put(err_buf, err_cap, r.err.empty() ? "no result" : r.err); return 1; }
+    if (out) memcpy(out, r.image->Data.data(), r.image->Data.size() * sizeof(float));
+    if (exposure_out) *exposure_out = r.image->Exposure;
+    return 0;
+}
+
+extern "C" const char *nl_host_op_stack_roundtrip_json(const char *json)
+{
+    using namespace nightlight;
+    static thread_local std::string out;
+    auto op = NewOpStackDefault();
+    std::string err;
+    if (!op->UnmarshalJSON(json ? json : "{}", &err)) { out = "error: " + err; return out.c_str(); }
+    out = op->MarshalJSON();
+    return out.c_str();
+}

@@ -1,0 +1,41 @@
+"""Python view of the host-side operator mirror (nightlight_amd/host/*.cpp):
+the reference's "stack" operator decoded from JSON and run through
+MakePromises/Apply (internal/ops/stack/stack.go:92-227)."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class OperatorError(RuntimeError):
+    pass
+
+
+def op_stack_roundtrip_json(text):
+    """UnmarshalJSON with the reference's defaults, then MarshalJSON."""
+    return capi.load().nl_host_op_stack_roundtrip_json(text.encode()).decode()
+
+
+def op_stack_apply_json(text, frames, width, height, exposure=None, hfr=None, device=0,
+                        max_threads=4):
+    """frames: list of full-image float32 arrays, None = frame skipped upstream.
+    Returns (result, exposure_sum, log)."""
+    lib = capi.load()
+    f32p = C.POINTER(C.c_float)
+    keep = [None if f is None else np.ascontiguousarray(f, np.float32).reshape(-1) for f in frames]
+    ptrs = (f32p * max(len(keep), 1))(*[None if k is None else k.ctypes.data_as(f32p) for k in keep])
+    out = np.zeros(width * height, np.float32)
+    exp_out = C.c_float(0)
+    log = C.create_string_buffer(4096)
+    err = C.create_string_buffer(1024)
+    e = None if exposure is None else np.ascontiguousarray(exposure, np.float32)
+    h = None if hfr is None else np.ascontiguousarray(hfr, np.float32)
+    rc = lib.nl_host_op_stack_apply_json(text.encode(), len(keep), int(width), int(height), ptrs,
+                                         None if e is None else capi.fptr(e),
+                                         None if h is None else capi.fptr(h),
+                                         int(device), int(max_threads), capi.fptr(out),
+                                         C.byref(exp_out), log, len(log), err, len(err))
+    if rc != 0:
+        raise OperatorError(err.value.decode())
+    return out, float(exp_out.value), log.value.decode()

@@ -67,6 +67,21 @@ def cpu_baseline(st, args, rows):
                       % (rows, w, n, MODE_NAMES[args.mode], dt)}, res, (cl, ch)
 
 
+def measured_traffic(kernel, args):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes
+    (profiles/r01_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction),
+    or None when this workload was not profiled."""
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+    except Exception:
+        return None
+    for e in doc.get("entries", []):
+        if (e["kernel"] == kernel and e["frames"] == args.frames and e["width"] == args.width
+                and e["rows"] == args.height and e["mode"] == args.mode):
+            return e["traffic_bytes"]
+    return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -143,7 +158,8 @@ def main():
                        "clip_high": int(counters[1].item()) if dist is not None else ch},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None, "kernel": st.last_kernel_name,
+                         "traffic": measured_traffic(st.last_kernel_name, args),
+                         "kernel": st.last_kernel_name,
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes": alg_bytes,
                          "pixels_redone_by_exact_kernel": st.last_fallback_pixels},
         }

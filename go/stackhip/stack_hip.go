@@ -1,0 +1,103 @@
+// Package stack -- drop-in replacement for the reference's
+// internal/ops/stack/stack.go that runs OpStack.Apply on an AMD MI355X through
+// libnlstack.so (C ABI: include/nlstack.h).
+//
+// NOT compiled in the build image (no Go toolchain there): this file is the
+// binding a Nightlight maintainer adds.  It keeps the package name, the
+// operator type string "stack", the JSON fields, the constructor names and the
+// Apply signature of the reference (stack.go:66-115), so cmd/nightlight/main.go
+// and internal/ops/stack/stackbatches.go compile against it unchanged.  Build
+// with:  go build -tags=jsoniter,hip ./cmd/nightlight   (and drop stack.go's
+// Apply behind `//go:build !hip`).
+//
+//go:build hip
+
+package stack
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../nightlight_amd -lnlstack -Wl,-rpath,${SRCDIR}/../../nightlight_amd
+#include <stdlib.h>
+#include "nlstack.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"fmt"
+	"unsafe"
+
+	"github.com/mlnoga/nightlight/internal/fits"
+	"github.com/mlnoga/nightlight/internal/ops"
+)
+
+// Device selects the GPU this process stacks on (one process per GPU).
+var Device = 0
+
+func lastError() error { return errors.New(C.GoString(C.nl_last_error())) }
+
+// Apply stacks a set of light frames on the GPU.  Same contract as
+// internal/ops/stack/stack.go:115-227: mode validation and auto selection,
+// weights from getWeights (kept in Go, stack.go:231-270), one result image with
+// the summed exposure, the "Clipped low ..." log line from the counters.
+func (op *OpStack) Apply(f []*fits.Image, c *ops.Context) (result *fits.Image, err error) {
+	mode := op.Mode
+	if mode < StMedian || mode > StAuto {
+		return nil, errors.New("invalid stacking mode")
+	}
+	if mode == StAuto {
+		mode = autoSelectStackingMode(len(f))
+	}
+	fmt.Fprintf(c.Log, "Stacking %d frames with stacking mode %d and sigma low %g high %g:\n",
+		len(f), mode, op.SigmaLow, op.SigmaHigh)
+
+	weights, err := getWeights(f, op.Weighting)
+	if err != nil {
+		return nil, err
+	}
+	if mode == StMADSigma && weights != nil {
+		return nil, errors.New("MADSigma stacking with weights is still unimplemented") // reference panics, stack.go:185
+	}
+
+	width, height := int(f[0].Naxisn[0]), len(f[0].Data)/int(f[0].Naxisn[0])
+	h := C.nl_stack_create(C.int(len(f)), C.int(width), C.int(height), 0, C.int(height), C.int(Device))
+	if h == nil {
+		return nil, lastError()
+	}
+	defer C.nl_stack_destroy(h)
+
+	// one cgo call per Go slice: [][]float32 cannot cross cgo, and the copy
+	// builds the planar [N][H*W] device layout on the way
+	for i, l := range f {
+		if rc := C.nl_stack_upload_frame(h, C.int(i), (*C.float)(unsafe.Pointer(&l.Data[0]))); rc != C.NL_OK {
+			return nil, lastError()
+		}
+	}
+	var wp *C.float
+	if weights != nil {
+		wp = (*C.float)(unsafe.Pointer(&weights[0]))
+	}
+	if rc := C.nl_stack_set_weights(h, wp); rc != C.NL_OK {
+		return nil, lastError()
+	}
+
+	data := make([]float32, len(f[0].Data))
+	var clipLow, clipHigh C.int64_t
+	if rc := C.nl_stack_run(h, C.int(mode), C.float(op.SigmaLow), C.float(op.SigmaHigh), C.float(op.RefFrameLoc),
+		(*C.float)(unsafe.Pointer(&data[0])), &clipLow, &clipHigh); rc != C.NL_OK {
+		return nil, lastError()
+	}
+	if mode >= StSigma {
+		fmt.Fprintf(c.Log, "Clipped low %d (%.2f%%) high %d (%.2f%%)\n",
+			int64(clipLow), float32(clipLow)*100.0/(float32(len(data)*len(f))),
+			int64(clipHigh), float32(clipHigh)*100.0/(float32(len(data)*len(f))))
+	}
+
+	exposureSum := float32(0)
+	for _, l := range f {
+		exposureSum += l.Exposure
+	}
+	stack := fits.NewImageFromNaxisn(f[0].Naxisn, data)
+	stack.Exposure = exposureSum
+	return stack, nil
+}

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 result databases into the small text summaries committed
+under profiles/ (kernel-trace stats and per-kernel PMC averages)."""
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def kernel_stats(path):
+    db = sqlite3.connect(path)
+    rows = list(db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
+    out = ["# rocprofv3 --kernel-trace --stats  (durations in us)  source: %s" % path,
+           "%-88s %6s %12s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "%")]
+    for name, calls, total, avg, pct in rows:
+        out.append("%-88s %6d %12.1f %10.1f %6.2f" % (name[:88], calls, total, avg, pct))
+    return "\n".join(out)
+
+
+def pmc(path):
+    db = sqlite3.connect(path)
+    per = defaultdict(float)
+    for k, c, v, d in db.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection"):
+        per[(k, c, d)] += v
+    acc = defaultdict(lambda: defaultdict(list))
+    for (k, c, d), v in per.items():
+        acc[k][c].append(v)
+    out = ["# rocprofv3 --pmc  (per-dispatch sums over all XCDs/SEs, averaged over dispatches)  source: %s" % path]
+    for k, cs in acc.items():
+        if not k.startswith(("void nl::", "nl::")):
+            continue
+        out.append(k[:100])
+        for c, vs in sorted(cs.items()):
+            out.append("    %-24s dispatches=%d avg=%.6g" % (c, len(vs), sum(vs) / len(vs)))
+    return "\n".join(out)
+
+
+if __name__ == "__main__":
+    mode, path = sys.argv[1], sys.argv[2]
+    print(kernel_stats(path) if mode == "stats" else pmc(path))

@@ -123,6 +123,9 @@ int nl_stack_last_mode(nl_stack_t *h);
 /* GPU time of the last pass's kernels in ms, from HIP events recorded on the
  * handle's stream around the launches (valid after finish/run). */
 float nl_stack_last_kernel_ms(nl_stack_t *h);
+/* Same, for the dominant kernel of the pass alone (the one named by
+ * nl_stack_last_kernel_name); the difference is the hand-over passes. */
+float nl_stack_last_dominant_kernel_ms(nl_stack_t *h);
 /* on != 0: run every mode with the bit-exact kernels only (per-pixel replay
  * of the reference's permutation; slow, used for verification).  Default 0:
  * sigma clipping uses the register-resident kernel, which keeps the clip

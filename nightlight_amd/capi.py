@@ -34,7 +34,8 @@ EXPORTS = [
     "nl_stack_attach_device_frames", "nl_stack_fill_synthetic", "nl_stack_download_tile",
     "nl_stack_set_weights", "nl_weights_from_scalars",
     "nl_stack_run", "nl_stack_run_async", "nl_stack_finish", "nl_stack_result_device_ptr",
-    "nl_stack_last_mode", "nl_stack_last_kernel_ms", "nl_stack_last_kernel_name",
+    "nl_stack_last_mode", "nl_stack_last_kernel_ms", "nl_stack_last_dominant_kernel_ms",
+    "nl_stack_last_kernel_name",
     "nl_stack_set_exact", "nl_stack_last_fallback_pixels",
     "nl_stack_find_sigmas", "nl_stack_accumulate", "nl_stack_accumulate_finalize",
     "nl_stack_frame_stats", "nl_stack_frame_noise", "nl_stack_weights_from_noise",
@@ -96,6 +97,8 @@ def load():
     L.nl_stack_last_mode.argtypes = [vp]
     L.nl_stack_last_kernel_ms.argtypes = [vp]
     L.nl_stack_last_kernel_ms.restype = C.c_float
+    L.nl_stack_last_dominant_kernel_ms.argtypes = [vp]
+    L.nl_stack_last_dominant_kernel_ms.restype = C.c_float
     L.nl_stack_last_kernel_name.argtypes = [vp]
     L.nl_stack_last_kernel_name.restype = C.c_char_p
     L.nl_stack_set_exact.argtypes = [vp, C.c_int]

@@ -57,7 +57,8 @@ struct nl_stack {
     int n_frames = 0, width = 0, height = 0, row0 = 0, rows = 0;
     int64_t npix = 0;                 // rows*width
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;      // whole pass
+    hipEvent_t ev_dom0 = nullptr, ev_dom1 = nullptr;        // dominant kernel only
     float *d_frames_owned = nullptr;  // [n_frames][npix]
     float *d_frames = nullptr;        // owned or lent
     float *d_out = nullptr;           // [npix]
@@ -111,6 +112,8 @@ static int destroy_impl(nl_stack_t *h)
     if (h->d_stat_partial) (void)hipFree(h->d_stat_partial);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+    if (h->ev_dom0) (void)hipEventDestroy(h->ev_dom0);
+    if (h->ev_dom1) (void)hipEventDestroy(h->ev_dom1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return NL_OK;
@@ -131,6 +134,8 @@ static int create_impl(nl_stack_t *h)
     NL_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     NL_HIP(hipEventCreate(&h->ev_start));
     NL_HIP(hipEventCreate(&h->ev_stop));
+    NL_HIP(hipEventCreate(&h->ev_dom0));
+    NL_HIP(hipEventCreate(&h->ev_dom1));
     const size_t frame_bytes = (size_t)h->npix * sizeof(float);
     NL_HIP(hipMalloc(&h->d_frames_owned, frame_bytes * (size_t)h->n_frames));
     h->d_frames = h->d_frames_owned;
@@ -332,9 +337,17 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
 
     NL_HIP(hipEventRecord(h->ev_start, h->stream));
     NL_HIP(hipMemsetAsync(h->d_partial, 0, kScratchBytes, h->stream));
+    NL_HIP(hipEventRecord(h->ev_dom0, h->stream));
     if (mode == NL_ST_MEAN) {
         NL_HIP(nl::launch_stack_mean(weighted, a, h->stream, &h->last_kernel));
+        NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
         h->last_has_counters = false;
+    } else if (!h->force_exact && mode == NL_ST_MEDIAN && nl::fast_supported(mode, weighted, a.n_frames)) {
+        // register-resident sorting network: bit-exact, nothing to hand over
+        NL_HIP(nl::launch_stack_median_fast(a, h->stream, &h->last_kernel));
+        NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
+        h->last_has_counters = false;
+        h->last_used_fast = false;
     } else if (!h->force_exact && h->d_fb_list && nl::fast_supported(mode, weighted, a.n_frames)) {
         // register-resident fast kernel; pixels it cannot decide go to the exact kernel
         nl::FastArgs f;
@@ -348,7 +361,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         f.in_count = nullptr;
         f.in_capacity = 0;
         int fast_grid = 0;
-        NL_HIP(nl::launch_stack_sigma_fast(a, f, &fast_grid, h->stream, &h->last_kernel));
+        NL_HIP(nl::launch_stack_sigma_fast(a, f, &fast_grid, h->stream, &h->last_kernel, h->ev_dom1));
         int lanes = 0;
         size_t lds = 0;
         if (nl::exact_plan(mode, weighted, a.n_frames, a.n_pad, kListLanes, &lanes, &lds) != 0)
@@ -373,6 +386,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         a.tiles = (a.npix + lanes - 1) / lanes;
         int grid = (int)(a.tiles < (int64_t)h->max_grid ? a.tiles : (int64_t)h->max_grid);
         NL_HIP(nl::launch_stack_exact(mode, weighted, a, lanes, grid, lds, h->stream, &h->last_kernel));
+        NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
         NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
         h->last_has_counters = (mode != NL_ST_MEDIAN);
     }
@@ -404,6 +418,16 @@ int nl_stack_run(nl_stack_t *h, int mode, float sigma_low, float sigma_high, flo
     int rc = nl_stack_run_async(h, mode, sigma_low, sigma_high, ref_loc);
     if (rc != NL_OK) return rc;
     return nl_stack_finish(h, out_host, clip_low, clip_high);
+}
+
+float nl_stack_last_dominant_kernel_ms(nl_stack_t *h)
+{
+    if (!h || !h->ev_dom0) return -1.0f;
+    if (hipSetDevice(h->device) != hipSuccess) return -1.0f;
+    if (hipEventSynchronize(h->ev_dom1) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, h->ev_dom0, h->ev_dom1) != hipSuccess) return -1.0f;
+    return ms;
 }
 
 int nl_stack_set_exact(nl_stack_t *h, int on)

@@ -150,6 +150,56 @@ __device__ __forceinline__ int opaque(int x)
     return x;
 }
 
+// Gather one pixel's samples into registers and sort them ascending; returns
+// the number of valid samples n (they occupy v[0..n), +Inf above).
+// NaN = no data (stack.go:380-387): NaNs and unused positions (k >= N) become
+// +Inf and sort last.  All loads are issued first (independent, 256 B per wave
+// each); the frame pointer advances by one frame per position and stops at the
+// last frame, so unused positions re-read a valid address.
+template <int NS>
+__device__ __forceinline__ int gather_sorted(const float *frames, int64_t stride, int N,
+                                             unsigned boff, float (&v)[NS])
+{
+    {
+        const char *fk = reinterpret_cast<const char *>(frames);
+        const int64_t frame_bytes = stride * (int64_t)sizeof(float);
+        static_chunks<0, NS, 16>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            v[k] = *reinterpret_cast<const float *>(fk + boff);
+            fk += (k + 1 < N) ? frame_bytes : 0;
+        });
+    }
+    int nan_cnt = 0;
+    static_chunks<0, NS, 16>([&](auto K) NL_INL {
+        constexpr int k = decltype(K)::value;
+        float x = v[k];
+        x = (k < N) ? x : __builtin_nanf("");
+        nan_cnt += (x != x) ? 1 : 0;
+        v[k] = fminf(x, __builtin_inff());          // minnum(NaN, Inf) = Inf
+    });
+    sort_network<NS>(v);
+    return NS - nan_cnt;
+}
+
+// StackMedian (stack.go:274-303): the median is order independent, so the
+// sorted register column gives it exactly (qsort.go:68-82: odd n -> middle,
+// even n -> 0.5*(lower+upper)).  Bit-exact, no hand-over lists.
+template <int NS>
+__global__ __launch_bounds__(256) void stack_median_fast_kernel(StackArgs p)
+{
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = pix < p.npix;
+    const unsigned boff = (unsigned)(on ? pix : 0) * 4u;
+    float v[NS];
+    const int n = gather_sorted<NS>(p.frames, p.stride, p.n_frames, boff, v);
+    const int kk = n >> 1;
+    const float upper = pick<0, NS>(v, kk);
+    const float lower = pick<0, NS>(v, kk > 0 ? kk - 1 : 0);
+    float res = (n & 1) ? upper : 0.5f * (lower + upper);
+    if (n == 0) res = p.ref_loc;
+    if (on) p.out[pix] = res;
+}
+
 // ZONAL = true : grid covers the tile, lane = pixel blockIdx*256+thread;
 // ZONAL = false: grid-stride over q.in_list (pixels handed over by the zonal
 //                kernel), any number of missing / clipped samples.
@@ -181,34 +231,11 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         if (listed) pix = on ? (int64_t)q.in_list[item] : 0;
         const unsigned boff = (unsigned)(on ? pix : 0) * 4u;     // byte offset inside a frame
 
-        // ---- gather: all loads first (independent, 256 B per wave each); the
-        // frame pointer advances by one frame per position and stops at the
-        // last frame, so unused positions (k >= N) re-read a valid address ----
+        // A genuine +-Inf sample stays among the n valid ones, makes the variance
+        // non-finite and thereby sends the pixel to the exact kernel (`bail`).
         float v[NS];
-        {
-            const char *fk = reinterpret_cast<const char *>(p.frames);
-            const int64_t frame_bytes = p.stride * (int64_t)sizeof(float);
-            static_chunks<0, NS, 16>([&](auto K) NL_INL {
-                constexpr int k = decltype(K)::value;
-                v[k] = *reinterpret_cast<const float *>(fk + boff);
-                fk += (k + 1 < N) ? frame_bytes : 0;
-            });
-        }
-        // NaN = no data (stack.go:380-387): NaNs and unused positions become
-        // +Inf and sort last.  A genuine +-Inf sample stays among the n valid
-        // ones, makes the variance non-finite and thereby sends the pixel to
-        // the exact kernel (the `bail` test below).
-        int nan_cnt = 0;
-        static_chunks<0, NS, 16>([&](auto K) NL_INL {
-            constexpr int k = decltype(K)::value;
-            float x = v[k];
-            x = (k < N) ? x : __builtin_nanf("");
-            nan_cnt += (x != x) ? 1 : 0;
-            v[k] = fminf(x, __builtin_inff());          // minnum(NaN, Inf) = Inf
-        });
-        const int n = NS - nan_cnt;
+        const int n = gather_sorted<NS>(p.frames, p.stride, N, boff, v);
         bool to_exact = false;
-        sort_network<NS>(v);
 
         float res = p.ref_loc;
         int c_lo = 0, c_hi = 0;
@@ -421,13 +448,37 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
 
 int fast_supported(int mode, bool weighted, int n_frames)
 {
-    return (mode == NL_ST_SIGMA && !weighted && n_frames >= 2 && n_frames <= 128) ? 1 : 0;
+    if (n_frames < 2 || n_frames > 128) return 0;
+    if (mode == NL_ST_MEDIAN) return 1;
+    return (mode == NL_ST_SIGMA && !weighted) ? 1 : 0;
+}
+
+template <int NS>
+static void launch_median(const StackArgs &args, unsigned blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(stack_median_fast_kernel<NS>, dim3(blocks), dim3(256), 0, stream, args);
+}
+
+hipError_t launch_stack_median_fast(const StackArgs &args, hipStream_t stream, const char **name)
+{
+    const unsigned blocks = (unsigned)((args.npix + 255) / 256);
+    const int n = args.n_frames;
+    if (n <= 8)        { *name = "stack_median_fast_kernel<8>";   launch_median<8>(args, blocks, stream); }
+    else if (n <= 16)  { *name = "stack_median_fast_kernel<16>";  launch_median<16>(args, blocks, stream); }
+    else if (n <= 32)  { *name = "stack_median_fast_kernel<32>";  launch_median<32>(args, blocks, stream); }
+    else if (n <= 48)  { *name = "stack_median_fast_kernel<48>";  launch_median<48>(args, blocks, stream); }
+    else if (n <= 64)  { *name = "stack_median_fast_kernel<64>";  launch_median<64>(args, blocks, stream); }
+    else if (n <= 80)  { *name = "stack_median_fast_kernel<80>";  launch_median<80>(args, blocks, stream); }
+    else if (n <= 96)  { *name = "stack_median_fast_kernel<96>";  launch_median<96>(args, blocks, stream); }
+    else if (n <= 112) { *name = "stack_median_fast_kernel<112>"; launch_median<112>(args, blocks, stream); }
+    else               { *name = "stack_median_fast_kernel<128>"; launch_median<128>(args, blocks, stream); }
+    return hipGetLastError();
 }
 
 
 template <int NS>
 static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned tile_blocks,
-                        int *blocks_used, hipStream_t stream)
+                        int *blocks_used, hipStream_t stream, hipEvent_t dominant_done)
 {
     FastArgs f = fargs;
     f.in_list = nullptr;
@@ -436,6 +487,7 @@ static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned t
     if constexpr (NS >= 48) {
         hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true>), dim3(tile_blocks), dim3(256), 0,
                            stream, args, f);
+        if (dominant_done) (void)hipEventRecord(dominant_done, stream);
         // generic pass over the pixels the zonal waves handed over (its length
         // is only known on the device: fixed grid, grid-stride loop)
         f.in_list = fargs.gen_list;
@@ -448,26 +500,27 @@ static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned t
         // small stacks: generic passes are cheap, run them over the whole tile
         hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false>), dim3(tile_blocks), dim3(256), 0,
                            stream, args, f);
+        if (dominant_done) (void)hipEventRecord(dominant_done, stream);
     }
     *blocks_used = 0;
 }
 
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, int *blocks_used,
-                                   hipStream_t stream, const char **name)
+                                   hipStream_t stream, const char **name, hipEvent_t dominant_done)
 {
     const unsigned blocks = (unsigned)((args.npix + 255) / 256);
     const int n = args.n_frames;
     // network sizes: the frame count rounded up to the next instantiated size;
     // unused positions count as missing samples
-    if (n <= 8)        { *name = "stack_sigma_fast_kernel<8>";   launch_pair<8>(args, fargs, blocks, blocks_used, stream); }
-    else if (n <= 16)  { *name = "stack_sigma_fast_kernel<16>";  launch_pair<16>(args, fargs, blocks, blocks_used, stream); }
-    else if (n <= 32)  { *name = "stack_sigma_fast_kernel<32>";  launch_pair<32>(args, fargs, blocks, blocks_used, stream); }
-    else if (n <= 48)  { *name = "stack_sigma_fast_kernel<48>";  launch_pair<48>(args, fargs, blocks, blocks_used, stream); }
-    else if (n <= 64)  { *name = "stack_sigma_fast_kernel<64>";  launch_pair<64>(args, fargs, blocks, blocks_used, stream); }
-    else if (n <= 80)  { *name = "stack_sigma_fast_kernel<80>";  launch_pair<80>(args, fargs, blocks, blocks_used, stream); }
-    else if (n <= 96)  { *name = "stack_sigma_fast_kernel<96>";  launch_pair<96>(args, fargs, blocks, blocks_used, stream); }
-    else if (n <= 112) { *name = "stack_sigma_fast_kernel<112>"; launch_pair<112>(args, fargs, blocks, blocks_used, stream); }
-    else               { *name = "stack_sigma_fast_kernel<128>"; launch_pair<128>(args, fargs, blocks, blocks_used, stream); }
+    if (n <= 8)        { *name = "stack_sigma_fast_kernel<8>";   launch_pair<8>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    else if (n <= 16)  { *name = "stack_sigma_fast_kernel<16>";  launch_pair<16>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    else if (n <= 32)  { *name = "stack_sigma_fast_kernel<32>";  launch_pair<32>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    else if (n <= 48)  { *name = "stack_sigma_fast_kernel<48>";  launch_pair<48>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    else if (n <= 64)  { *name = "stack_sigma_fast_kernel<64>";  launch_pair<64>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    else if (n <= 80)  { *name = "stack_sigma_fast_kernel<80>";  launch_pair<80>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    else if (n <= 96)  { *name = "stack_sigma_fast_kernel<96>";  launch_pair<96>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    else if (n <= 112) { *name = "stack_sigma_fast_kernel<112>"; launch_pair<112>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    else               { *name = "stack_sigma_fast_kernel<128>"; launch_pair<128>(args, fargs, blocks, blocks_used, stream, dominant_done); }
     return hipGetLastError();
 }
 

@@ -54,8 +54,10 @@ hipError_t launch_reduce_counters(const unsigned long long *partial, int n_block
 
 // ---- stack_fast.hip ----
 int fast_supported(int mode, bool weighted, int n_frames);
+hipError_t launch_stack_median_fast(const StackArgs &args, hipStream_t stream, const char **name);
+// dominant_done (optional) is recorded right after the first, dominant kernel
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, int *blocks_used,
-                                   hipStream_t stream, const char **name);
+                                   hipStream_t stream, const char **name, hipEvent_t dominant_done);
 
 // ---- stack_mean.hip ----
 hipError_t launch_stack_mean(bool weighted, const StackArgs &args, hipStream_t stream,

@@ -132,6 +132,10 @@ class StackHandle:
         return float(self._lib.nl_stack_last_kernel_ms(self._h))
 
     @property
+    def last_dominant_kernel_ms(self):
+        return float(self._lib.nl_stack_last_dominant_kernel_ms(self._h))
+
+    @property
     def last_kernel_name(self):
         return self._lib.nl_stack_last_kernel_name(self._h).decode()
 

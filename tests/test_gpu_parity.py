@@ -69,6 +69,18 @@ def test_fast_sigma_counts_exact_values_close(nl, oracle, n, kappa):
     assert np.max(np.abs(got[ok] - want[ok]) / np.abs(want[ok])) < 2e-6
 
 
+@pytest.mark.parametrize("n", [2, 3, 8, 9, 16, 31, 32, 47, 64, 65, 100, 128])
+def test_fast_median_is_bit_exact(nl, oracle, n):
+    # default dispatch for the median: register-resident sorting network; the
+    # median is order independent, so it must equal the oracle bit for bit
+    width, height = 131, 23
+    frames = make_frames(n, width, height, seed=500 + n, ties=(n % 3 == 0))
+    frames[0, 7] = np.inf
+    frames[n - 1, 9] = -np.inf
+    got, _, want, _ = run_both(nl, oracle, 0, frames, width, height, None, 0, 0, exact=False)
+    assert same_values(got, want), "fast median n=%d: %s" % (n, describe_mismatch(got, want))
+
+
 def test_fast_sigma_clean_frames_no_nan(nl, oracle):
     # no missing samples at all: every wave stays in the zonal passes
     width, height, n = 256, 64, 128

@@ -127,7 +127,9 @@ float nl_stack_last_kernel_ms(nl_stack_t *h);
  * nl_stack_last_kernel_name); the difference is the hand-over passes. */
 float nl_stack_last_dominant_kernel_ms(nl_stack_t *h);
 /* on != 0: run every mode with the bit-exact kernels only (per-pixel replay
- * of the reference's permutation; slow, used for verification).  Default 0:
+ * of the reference's permutation; slow, used for verification; 1 = one pixel
+ * per lane with the column in LDS, 2 = one wavefront per pixel where that
+ * variant exists, i.e. unweighted sigma clipping).  Default 0:
  * sigma clipping uses the register-resident kernel, which keeps the clip
  * counters identical to the reference's and the output within summation-order
  * rounding, and hands undecidable pixels to the exact kernel. */

@@ -1,0 +1,123 @@
+// fast_common.hpp -- compile-time building blocks shared by the register-resident
+// kernels (stack_fast.hip, stack_fast_ml.hip): static loops, the odd-even merge
+// sorting network, per-lane picks from a register column.
+#pragma once
+#include <type_traits>
+#include <utility>
+
+#include "stack_kernels.h"
+
+namespace nl {
+
+constexpr float kU = 5.9604644775390625e-8f;   // 2^-24, fp32 unit roundoff
+constexpr int kZone = 8;      // sorted positions per side that may be clipped in the zonal path
+constexpr int kPadMax = 8;    // missing samples (NaN) a lane may have in the zonal path
+constexpr unsigned kGenericGrid = 2048;   // workgroups of the generic pass over the hand-over list
+
+// compile-time loops: every index is a constant, so register columns never
+// fall back to scratch memory (pragma unroll gives up on the large networks)
+template <int B, int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f)
+{
+    (f(std::integral_constant<int, B + I>{}), ...);
+}
+template <int B, int E, class F>
+__device__ __forceinline__ void static_range(F &&f)
+{
+    if constexpr (E > B) static_for_impl<B>(std::make_integer_sequence<int, E - B>{}, static_cast<F &&>(f));
+}
+// same, but the instruction scheduler may not move code across chunk
+// boundaries: keeps the live ranges of per-element temporaries (lane masks,
+// scalar addresses, differences) short in these very long basic blocks
+template <int B, int E, int CH, class F>
+__device__ __forceinline__ void static_chunks(F &&f)
+{
+    if constexpr (E > B) {
+        constexpr int M = (B + CH < E) ? B + CH : E;
+        static_for_impl<B>(std::make_integer_sequence<int, M - B>{}, f);
+        __builtin_amdgcn_sched_barrier(0);
+        static_chunks<M, E, CH>(static_cast<F &&>(f));
+    }
+}
+#define NL_INL __attribute__((always_inline))
+
+// ---- Batcher odd-even merge sort, generated at compile time -----------------
+// All comparators put the minimum at the lower index, so comparators touching
+// an index >= NS can simply be dropped: the network sorts NS elements for any
+// NS (not only powers of two).
+struct CePair { short lo, hi; };
+
+template <int NS>
+struct OemNetwork {
+    static constexpr int pow2()
+    {
+        int p = 1;
+        while (p < NS) p <<= 1;
+        return p;
+    }
+    static constexpr int count()
+    {
+        int c = 0;
+        const int P2 = pow2();
+        for (int p = 1; p < P2; p <<= 1)
+            for (int k = p; k >= 1; k >>= 1)
+                for (int j = k % p; j + k < P2; j += 2 * k)
+                    for (int i = 0; i < k; i++)
+                        if ((i + j) / (2 * p) == (i + j + k) / (2 * p) && (i + j + k) < NS) c++;
+        return c;
+    }
+    static constexpr int kCount = count();
+    struct Table { CePair e[kCount > 0 ? kCount : 1]; };
+    static constexpr Table make()
+    {
+        Table t{};
+        int c = 0;
+        const int P2 = pow2();
+        for (int p = 1; p < P2; p <<= 1)
+            for (int k = p; k >= 1; k >>= 1)
+                for (int j = k % p; j + k < P2; j += 2 * k)
+                    for (int i = 0; i < k; i++)
+                        if ((i + j) / (2 * p) == (i + j + k) / (2 * p) && (i + j + k) < NS) {
+                            t.e[c].lo = (short)(i + j);
+                            t.e[c].hi = (short)(i + j + k);
+                            c++;
+                        }
+        return t;
+    }
+    static constexpr Table kTable = make();
+};
+
+template <int NS>
+__device__ __forceinline__ void sort_network(float (&v)[NS])
+{
+    using Net = OemNetwork<NS>;
+    static_chunks<0, Net::kCount, 64>([&](auto I) NL_INL {
+        constexpr CePair ce = Net::kTable.e[decltype(I)::value];
+        const float lo = fminf(v[ce.lo], v[ce.hi]);
+        const float hi = fmaxf(v[ce.lo], v[ce.hi]);
+        v[ce.lo] = lo;
+        v[ce.hi] = hi;
+    });
+}
+
+// value at a per-lane position idx, known to lie in [B, E)
+template <int B, int E, int NS>
+__device__ __forceinline__ float pick(const float (&v)[NS], int idx)
+{
+    float r = v[B];
+    static_range<B + 1, E>([&](auto K) NL_INL {
+        constexpr int k = decltype(K)::value;
+        r = (idx == k) ? v[k] : r;
+    });
+    return r;
+}
+
+// the compiler must not share the 'rank in [a,b)' masks between passes: 128
+// live lane masks would spill the SGPR file
+__device__ __forceinline__ int opaque(int x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+}  // namespace nl

@@ -39,6 +39,7 @@ int fail(int code, const char *fmt, ...)
 
 constexpr int kStatBlocks = 2048;
 constexpr int kListGrid = 2048;     // workgroups of the exact kernel in fallback-list mode
+constexpr int kCoopGrid = 16384;    // workgroups (one wave each) of the wave-per-pixel exact replay
 constexpr int kListLanes = 4;       // pixels per wave there: few pixels, keep divergence low
 // per-pass device scratch, zeroed by one memset: clip accumulators + the two list lengths
 constexpr size_t kScratchBytes = sizeof(unsigned long long) * (2 * nl::kClipSlots + 1);
@@ -71,6 +72,7 @@ struct nl_stack {
     unsigned *d_fb_count = nullptr;            // [2]: exact-list length, generic-list length (inside d_partial)
     unsigned *d_gen_list = nullptr;            // [npix] pixels zonal waves handed to the generic pass
     bool force_exact = false;
+    int exact_flavour = 0;            // nl_stack_set_exact argument: 1 = LDS column kernel, 2 = wave-per-pixel replay
     bool last_used_fast = false;
     unsigned long long *d_counters = nullptr;  // [2]
     double *d_stat_partial = nullptr;          // [kStatBlocks*3]
@@ -348,7 +350,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
         h->last_has_counters = false;
         h->last_used_fast = false;
-    } else if (!h->force_exact && h->d_fb_list && nl::fast_supported(mode, weighted, a.n_frames)) {
+    } else if (!h->force_exact && h->d_fb_list &&
+               (nl::fast_supported(mode, weighted, a.n_frames) || nl::fast_ml_supported(mode, weighted, a.n_frames))) {
         // register-resident fast kernel; pixels it cannot decide go to the exact kernel
         nl::FastArgs f;
         f.fb_list = h->d_fb_list;
@@ -361,21 +364,37 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         f.in_count = nullptr;
         f.in_capacity = 0;
         int fast_grid = 0;
-        NL_HIP(nl::launch_stack_sigma_fast(a, f, &fast_grid, h->stream, &h->last_kernel, h->ev_dom1));
-        int lanes = 0;
-        size_t lds = 0;
-        if (nl::exact_plan(mode, weighted, a.n_frames, a.n_pad, kListLanes, &lanes, &lds) != 0)
-            return fail(NL_ERR_TOO_MANY_FRAMES,
-                        "%d frames do not fit the per-pixel LDS column (mode %d)", a.n_frames, mode);
+        if (a.n_frames <= 128)
+            NL_HIP(nl::launch_stack_sigma_fast(a, f, &fast_grid, h->stream, &h->last_kernel, h->ev_dom1));
+        else   // 129..512 frames: 2 or 4 lanes per pixel
+            NL_HIP(nl::launch_stack_sigma_ml(a, f, h->stream, &h->last_kernel, h->ev_dom1));
+        // exact replay of the undecidable pixels: one wave per pixel where available
         nl::StackArgs e = a;
         e.list = h->d_fb_list;
         e.list_count = h->d_fb_count;
         e.list_capacity = (unsigned)h->npix;
         const char *exact_name = "";
-        NL_HIP(nl::launch_stack_exact(mode, weighted, e, lanes, kListGrid, lds, h->stream, &exact_name));
+        if (nl::coop_supported(mode, weighted, a.n_frames)) {
+            NL_HIP(nl::launch_stack_sigma_coop(e, kCoopGrid, h->stream, &exact_name));
+        } else {
+            int lanes = 0;
+            size_t lds = 0;
+            if (nl::exact_plan(mode, weighted, a.n_frames, a.n_pad, kListLanes, &lanes, &lds) != 0)
+                return fail(NL_ERR_TOO_MANY_FRAMES,
+                            "%d frames do not fit the per-pixel LDS column (mode %d)", a.n_frames, mode);
+            NL_HIP(nl::launch_stack_exact(mode, weighted, e, lanes, kListGrid, lds, h->stream, &exact_name));
+        }
         NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
         h->last_has_counters = true;
         h->last_used_fast = true;
+    } else if (h->exact_flavour == 2 && nl::coop_supported(mode, weighted, a.n_frames)) {
+        // verification: the wave-per-pixel exact replay over the whole tile
+        h->last_used_fast = false;
+        const int64_t g = a.npix < 65536 ? a.npix : 65536;
+        NL_HIP(nl::launch_stack_sigma_coop(a, (int)g, h->stream, &h->last_kernel));
+        NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
+        NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
+        h->last_has_counters = true;
     } else {
         h->last_used_fast = false;
         int lanes = 0;
@@ -434,6 +453,7 @@ int nl_stack_set_exact(nl_stack_t *h, int on)
 {
     NL_CHECK_HANDLE(h);
     h->force_exact = on != 0;
+    h->exact_flavour = on;
     return NL_OK;
 }
 

@@ -1,0 +1,206 @@
+// stack_exact_coop.hip -- bit-exact StackSigma replay, one WAVEFRONT per pixel.
+//
+// The register-resident kernels hand ~1e-4 of the pixels (a sample inside the
+// few-ulp clip window) to an exact replay.  With so few pixels the
+// one-pixel-per-lane kernel of stack_exact.hip is pure latency (a handful of
+// active lanes crawling through divergent loops); here the 64 lanes of a wave
+// cooperate on ONE pixel and still execute the reference's algorithm in the
+// reference's order, so every bit and both counters are unchanged:
+//   gather      stack.go:380-387   64 frames per step, order-preserving compaction (ballot + popcount)
+//   quickselect qsort.go:94-126    the two Hoare scans look at 64 elements at a time
+//                                  (ballot + find-first-set); swaps are single LDS writes
+//   mean/stddev stats.go:246-261   the fp32 sums stay sequential (v_readlane feeds one add chain);
+//                                  differences and squares are computed 64 at a time
+//   clip        stack.go:411-424   swap-with-last, same visiting order, clean stretches skipped 64 at a time
+// The pixel's column lives in LDS as a plain array (n_frames floats per wave).
+#include "stack_kernels.h"
+
+namespace nl {
+
+namespace {
+
+__device__ __forceinline__ float sqrt_like_go(float x)      // stats.go:259
+{
+    return (float)__builtin_sqrt((double)x);
+}
+
+__device__ __forceinline__ void lds_fence()
+{
+    __syncthreads();      // single-wave workgroup: orders LDS writes before later reads
+}
+
+// sequential fp32 sum of t[0..n) in index order; x = per-lane slice loader
+template <class F>
+__device__ __forceinline__ float seq_sum(int n, F &&elem)
+{
+    float s = 0.0f;
+    const int lane = threadIdx.x;
+    for (int base = 0; base < n; base += 64) {
+        const float x = elem(base + lane);              // lanes past n deliver garbage, never added
+        const int m = min(64, n - base);
+        int i = 0;
+        for (; i + 8 <= m; i += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i + u));
+        }
+        for (; i < m; i++) s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i));
+    }
+    return s;
+}
+
+// qsort.go:94-126 on a[0..n), k 1-based; all control values are wave-uniform
+__device__ float coop_select(float *a, int n, int k)
+{
+    const int lane = threadIdx.x;
+    int left = 0, right = n - 1;
+    while (left < right) {
+        const float pivot = a[(left + right) >> 1];
+        int l = left - 1, r = right + 1;
+        for (;;) {
+            // do l++ while !(a[l] >= pivot)
+            for (int base = l + 1;; base += 64) {
+                const int idx = base + lane;
+                const float x = idx <= right ? a[idx] : __builtin_inff();
+                const unsigned long long m = __ballot(x >= pivot);
+                if (m) { l = base + __builtin_ctzll(m); break; }
+            }
+            // do r-- while !(a[r] <= pivot)
+            for (int base = r - 1;; base -= 64) {
+                const int idx = base - lane;
+                const float x = idx >= left ? a[idx] : -__builtin_inff();
+                const unsigned long long m = __ballot(x <= pivot);
+                if (m) { r = base - __builtin_ctzll(m); break; }
+            }
+            if (l >= r) break;
+            const float al = a[l], ar = a[r];
+            lds_fence();
+            if (lane == 0) { a[l] = ar; a[r] = al; }
+            lds_fence();
+        }
+        const int offset = r - left + 1;
+        if (k <= offset) {
+            right = r;
+        } else {
+            left = r + 1;
+            k -= offset;
+        }
+    }
+    return a[left];
+}
+
+// qsort.go:68-82
+__device__ float coop_select_median(float *a, int n)
+{
+    const int k = (n >> 1) + 1;
+    const float upper = coop_select(a, n, k);
+    if (n & 1) return upper;
+    // max of a[0..k-2]
+    const int lane = threadIdx.x;
+    float lower = -__builtin_inff();
+    for (int base = 0; base < k - 1; base += 64) {
+        const int idx = base + lane;
+        if (idx < k - 1) lower = fmaxf(lower, a[idx]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lower = fmaxf(lower, __shfl_xor(lower, o, 64));
+    return 0.5f * (lower + upper);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
+{
+    extern __shared__ float a[];
+    const int lane = threadIdx.x;
+    const int N = p.n_frames;
+    int64_t limit = p.npix;
+    if (p.list) {
+        const unsigned cnt = *p.list_count;
+        limit = cnt < p.list_capacity ? cnt : p.list_capacity;
+    }
+    long long c_lo = 0, c_hi = 0;
+
+    for (int64_t item = blockIdx.x; item < limit; item += gridDim.x) {
+        const int64_t pix = p.list ? (int64_t)p.list[item] : item;
+        const float *fr = p.frames + pix;
+        lds_fence();
+        // ---- gather in frame order, NaN dropped (stack.go:380-387) ----
+        int n = 0;
+        for (int base = 0; base < N; base += 64) {
+            const int k = base + lane;
+            const float x = k < N ? fr[(int64_t)k * p.stride] : __builtin_nanf("");
+            const bool valid = x == x;
+            const unsigned long long m = __ballot(valid);
+            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+            if (valid) a[pos] = x;
+            n += __popcll(m);
+        }
+        lds_fence();
+
+        float res = p.ref_loc;
+        if (n > 0) {
+            for (;;) {
+                const float median = coop_select_median(a, n);
+                lds_fence();
+                // stats.go:246-261
+                const float fn = (float)n;
+                const float s = seq_sum(n, [&](int i) { return i < n ? a[i] : 0.0f; });
+                const float mean = s / fn;
+                const float vs = seq_sum(n, [&](int i) {
+                    const float d = (i < n ? a[i] : mean) - mean;
+                    return d * d;
+                });
+                const float var = vs / fn;
+                const float sd = sqrt_like_go(var);
+                const float t_lo = p.sig_lo * sd, t_hi = p.sig_hi * sd;
+                const float lo = median - t_lo, hi = median + t_hi;
+
+                // stack.go:411-424: swap-with-last, re-test the same index
+                const int before = n;
+                int j = 0;
+                while (j < n) {
+                    int found = -1;
+                    for (int base = j; base < n; base += 64) {
+                        const int idx = base + lane;
+                        const float x = idx < n ? a[idx] : 0.0f;
+                        const bool clipped = idx < n && (x < lo || x > hi);
+                        const unsigned long long m = __ballot(clipped);
+                        if (m) { found = base + __builtin_ctzll(m); break; }
+                    }
+                    if (found < 0) break;
+                    const float g = a[found];
+                    const float last = a[n - 1];
+                    if (g < lo) c_lo++; else c_hi++;
+                    lds_fence();
+                    if (lane == 0) a[found] = last;
+                    lds_fence();
+                    n--;
+                    j = found;
+                }
+                if (n == before || n <= 1) { res = mean; break; }
+            }
+        }
+        if (lane == 0) p.out[pix] = res;
+    }
+    if (lane == 0) {
+        unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+        if (c_lo) atomicAdd(slot + 0, (unsigned long long)c_lo);
+        if (c_hi) atomicAdd(slot + 1, (unsigned long long)c_hi);
+    }
+}
+
+int coop_supported(int mode, bool weighted, int n_frames)
+{
+    return (mode == NL_ST_SIGMA && !weighted && (size_t)n_frames * sizeof(float) <= 64 * 1024) ? 1 : 0;
+}
+
+hipError_t launch_stack_sigma_coop(const StackArgs &args, int grid, hipStream_t stream, const char **name)
+{
+    *name = "stack_sigma_coop_kernel";
+    hipLaunchKernelGGL(stack_sigma_coop_kernel, dim3(grid), dim3(64), (size_t)args.n_frames * sizeof(float),
+                       stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace nl

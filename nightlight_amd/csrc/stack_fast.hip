@@ -32,123 +32,9 @@
 // mask.  A wave that leaves this regime (NaN borders, heavy clipping) puts its
 // pixels on the "generic" list; the GENERIC instantiation re-does those from
 // the list with every position masked by its rank.
-#include <type_traits>
-#include <utility>
-
-#include "stack_kernels.h"
+#include "fast_common.hpp"
 
 namespace nl {
-
-constexpr float kU = 5.9604644775390625e-8f;   // 2^-24, fp32 unit roundoff
-constexpr int kZone = 8;      // sorted positions per side that may be clipped in the zonal path
-constexpr int kPadMax = 8;    // missing samples (NaN) a lane may have in the zonal path
-constexpr unsigned kGenericGrid = 2048;   // workgroups of the generic pass over the hand-over list
-
-// compile-time loops: every index is a constant, so register columns never
-// fall back to scratch memory (pragma unroll gives up on the large networks)
-template <int B, int... I, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f)
-{
-    (f(std::integral_constant<int, B + I>{}), ...);
-}
-template <int B, int E, class F>
-__device__ __forceinline__ void static_range(F &&f)
-{
-    if constexpr (E > B) static_for_impl<B>(std::make_integer_sequence<int, E - B>{}, static_cast<F &&>(f));
-}
-// same, but the instruction scheduler may not move code across chunk
-// boundaries: keeps the live ranges of per-element temporaries (lane masks,
-// scalar addresses, differences) short in these very long basic blocks
-template <int B, int E, int CH, class F>
-__device__ __forceinline__ void static_chunks(F &&f)
-{
-    if constexpr (E > B) {
-        constexpr int M = (B + CH < E) ? B + CH : E;
-        static_for_impl<B>(std::make_integer_sequence<int, M - B>{}, f);
-        __builtin_amdgcn_sched_barrier(0);
-        static_chunks<M, E, CH>(static_cast<F &&>(f));
-    }
-}
-#define NL_INL __attribute__((always_inline))
-
-// ---- Batcher odd-even merge sort, generated at compile time -----------------
-// All comparators put the minimum at the lower index, so comparators touching
-// an index >= NS can simply be dropped: the network sorts NS elements for any
-// NS (not only powers of two).
-struct CePair { short lo, hi; };
-
-template <int NS>
-struct OemNetwork {
-    static constexpr int pow2()
-    {
-        int p = 1;
-        while (p < NS) p <<= 1;
-        return p;
-    }
-    static constexpr int count()
-    {
-        int c = 0;
-        const int P2 = pow2();
-        for (int p = 1; p < P2; p <<= 1)
-            for (int k = p; k >= 1; k >>= 1)
-                for (int j = k % p; j + k < P2; j += 2 * k)
-                    for (int i = 0; i < k; i++)
-                        if ((i + j) / (2 * p) == (i + j + k) / (2 * p) && (i + j + k) < NS) c++;
-        return c;
-    }
-    static constexpr int kCount = count();
-    struct Table { CePair e[kCount > 0 ? kCount : 1]; };
-    static constexpr Table make()
-    {
-        Table t{};
-        int c = 0;
-        const int P2 = pow2();
-        for (int p = 1; p < P2; p <<= 1)
-            for (int k = p; k >= 1; k >>= 1)
-                for (int j = k % p; j + k < P2; j += 2 * k)
-                    for (int i = 0; i < k; i++)
-                        if ((i + j) / (2 * p) == (i + j + k) / (2 * p) && (i + j + k) < NS) {
-                            t.e[c].lo = (short)(i + j);
-                            t.e[c].hi = (short)(i + j + k);
-                            c++;
-                        }
-        return t;
-    }
-    static constexpr Table kTable = make();
-};
-
-template <int NS>
-__device__ __forceinline__ void sort_network(float (&v)[NS])
-{
-    using Net = OemNetwork<NS>;
-    static_chunks<0, Net::kCount, 64>([&](auto I) NL_INL {
-        constexpr CePair ce = Net::kTable.e[decltype(I)::value];
-        const float lo = fminf(v[ce.lo], v[ce.hi]);
-        const float hi = fmaxf(v[ce.lo], v[ce.hi]);
-        v[ce.lo] = lo;
-        v[ce.hi] = hi;
-    });
-}
-
-// value at a per-lane position idx, known to lie in [B, E)
-template <int B, int E, int NS>
-__device__ __forceinline__ float pick(const float (&v)[NS], int idx)
-{
-    float r = v[B];
-    static_range<B + 1, E>([&](auto K) NL_INL {
-        constexpr int k = decltype(K)::value;
-        r = (idx == k) ? v[k] : r;
-    });
-    return r;
-}
-
-// the compiler must not share the 'rank in [a,b)' masks between passes: 128
-// live lane masks would spill the SGPR file
-__device__ __forceinline__ int opaque(int x)
-{
-    asm volatile("" : "+v"(x));
-    return x;
-}
 
 // Gather one pixel's samples into registers and sort them ascending; returns
 // the number of valid samples n (they occupy v[0..n), +Inf above).
@@ -270,10 +156,15 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
             q_mid = (q0 + q1) + (q2 + q3);
         }
 
+        // max|x| over the survivors (only enters the reference-mean error term):
+        // first pass from the two ends of the sorted column, afterwards from the
+        // bounds every survivor passed
+        float amax = fmaxf(fabsf(v[0]), fabsf(pick<ZONAL ? ZH : 0, NS>(v, n - 1)));
+
         while (__any(active)) {
             const int cnt = b - a;
             const float fcnt = (float)cnt;
-            float dz0 = 0.0f, dz1 = 0.0f, qz0 = 0.0f, qz1 = 0.0f, amax;
+            float dz0 = 0.0f, dz1 = 0.0f, qz0 = 0.0f, qz1 = 0.0f;
             if constexpr (ZONAL) {
                 static_range<0, ZL>([&](auto K) NL_INL {
                     constexpr int k = decltype(K)::value;
@@ -287,11 +178,9 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                     dz1 += e;
                     qz1 = __builtin_fmaf(e, e, qz1);
                 });
-                // sorted: max|x| of the survivors is at one of the two ends
-                amax = fmaxf(fabsf(pick<0, ZL>(v, a)), fabsf(pick<ZH, NS>(v, b - 1)));
             } else {
                 const int a1 = opaque(a);
-                float sa = 0.0f, dz2 = 0.0f, dz3 = 0.0f, qz2 = 0.0f, qz3 = 0.0f;
+                float dz2 = 0.0f, dz3 = 0.0f, qz2 = 0.0f, qz3 = 0.0f;
                 static_chunks<0, NS / 4, 2>([&](auto K) NL_INL {
                     constexpr int k = 4 * decltype(K)::value;
                     const bool i0 = (unsigned)(k + 0 - a1) < (unsigned)cnt;
@@ -303,11 +192,8 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                     dz0 += e0; dz1 += e1; dz2 += e2; dz3 += e3;
                     qz0 = __builtin_fmaf(e0, e0, qz0); qz1 = __builtin_fmaf(e1, e1, qz1);
                     qz2 = __builtin_fmaf(e2, e2, qz2); qz3 = __builtin_fmaf(e3, e3, qz3);
-                    sa = fmaxf(fmaxf(sa, i0 ? fabsf(v[k + 0]) : 0.0f), i1 ? fabsf(v[k + 1]) : 0.0f);
-                    sa = fmaxf(fmaxf(sa, i2 ? fabsf(v[k + 2]) : 0.0f), i3 ? fabsf(v[k + 3]) : 0.0f);
                 });
                 dz0 += dz2; dz1 += dz3; qz0 += qz2; qz1 += qz3;
-                amax = sa;
             }
             const float dsum = d_mid + (dz0 + dz1);
             const float qsum = q_mid + (qz0 + qz1);
@@ -348,20 +234,23 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
             const float hi_min = fminf(ha, hb), hi_max = fmaxf(ha, hb);
 
             // ---- count certain clips (c1,d1) and possible clips (c2,d2) ----
+            // The column is sorted, so the samples below a threshold are a prefix and
+            // those above it a suffix (pads are +Inf): count over the whole zone
+            // without rank masks and subtract what is already excluded.
             int c1 = 0, c2 = 0, d1 = 0, d2 = 0;
             if constexpr (ZONAL) {
                 static_range<0, ZL>([&](auto K) NL_INL {
                     constexpr int k = decltype(K)::value;
-                    const bool in = k >= a;
-                    c1 += (in && v[k] < lo_min) ? 1 : 0;
-                    c2 += (in && v[k] < lo_max) ? 1 : 0;
+                    c1 += (v[k] < lo_min) ? 1 : 0;
+                    c2 += (v[k] < lo_max) ? 1 : 0;
                 });
                 static_range<ZH, NS>([&](auto K) NL_INL {
                     constexpr int k = decltype(K)::value;
-                    const bool in = k < b;
-                    d1 += (in && v[k] > hi_max) ? 1 : 0;
-                    d2 += (in && v[k] > hi_min) ? 1 : 0;
+                    d1 += (v[k] > hi_max) ? 1 : 0;
+                    d2 += (v[k] > hi_min) ? 1 : 0;
                 });
+                c1 = max(c1 - a, 0); c2 = max(c2 - a, 0);
+                d1 = max(d1 - (NS - b), 0); d2 = max(d2 - (NS - b), 0);
                 // the zones must still hold a survivor on each side, otherwise the
                 // next sorted position (outside the zone) might be clipped as well:
                 // such a lane restarts in the generic pass
@@ -370,16 +259,16 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                     active = false;
                 }
             } else {
-                const int a3 = opaque(a);
                 static_chunks<0, NS, 8>([&](auto K) NL_INL {
                     constexpr int k = decltype(K)::value;
-                    const bool in = (unsigned)(k - a3) < (unsigned)cnt;
                     const float x = v[k];
-                    c1 += (in && x < lo_min) ? 1 : 0;
-                    c2 += (in && x < lo_max) ? 1 : 0;
-                    d1 += (in && x > hi_max) ? 1 : 0;
-                    d2 += (in && x > hi_min) ? 1 : 0;
+                    c1 += (x < lo_min) ? 1 : 0;
+                    c2 += (x < lo_max) ? 1 : 0;
+                    d1 += (x > hi_max) ? 1 : 0;
+                    d2 += (x > hi_min) ? 1 : 0;
                 });
+                c1 = min(max(c1 - a, 0), cnt); c2 = min(max(c2 - a, 0), cnt);
+                d1 = min(max(d1 - (NS - b), 0), cnt); d2 = min(max(d2 - (NS - b), 0), cnt);
             }
             if (active) {
                 // a sample inside the window, or (negative sigma) inverted bounds where the
@@ -393,6 +282,7 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                     c_hi += d1;
                     a += c1;
                     b -= d1;
+                    amax = fminf(amax, fmaxf(fabsf(lo_min), fabsf(hi_max)));   // survivors lie in [lo_min, hi_max]
                     if ((c1 + d1) == 0 || (b - a) <= 1) {     // stack.go:427-430: mean BEFORE this pass
                         res = m;
                         active = false;

@@ -1,0 +1,457 @@
+// stack_fast_ml.hip -- register-resident sigma clipping for 129..512 frames:
+// LPP = 2 or 4 ADJACENT lanes share one pixel, each lane keeps 128 samples in
+// VGPRs (so the register footprint equals the 128-frame kernel's).
+//
+//   * lane role r loads frames [128 r, 128 r + 128) of the pixel;
+//   * each lane sorts its 128 values with the odd-even merge network;
+//   * the 2 (4) sorted runs are merged across lanes with bitonic merge stages:
+//     the cross-lane compare-exchanges read the partner's register through a
+//     DPP quad permute (no LDS), the remaining stages are in-lane;
+//     afterwards lane r holds the pixel's sorted ranks [128 r, 128 r + 128);
+//   * everything after the sort is the algorithm of stack_fast.hip (exact
+//     median by rank lookup, shifted moments, rigorous bracket of the
+//     reference's stddev, clip decisions accepted only when unambiguous, exact
+//     kernel for the rest -- see that file and DESIGN.md section 5); sums,
+//     counts and lookups are combined over the quad with DPP adds / ors, which
+//     are commutative, so all lanes of a pixel hold bit-identical values and
+//     take the same branches.
+//
+// StackSigma: internal/ops/stack/stack.go:372-436.  HBM traffic: every sample is
+// read once; a wave instruction covers 64/LPP consecutive pixels of LPP frames.
+#include "fast_common.hpp"
+
+namespace nl {
+
+constexpr int kMlNS = 128;     // samples per lane
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int x)
+{
+    return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true);
+}
+constexpr int kSwap1 = 0xB1;   // quad_perm [1,0,3,2]: partner = lane ^ 1
+constexpr int kSwap2 = 0x4E;   // quad_perm [2,3,0,1]: partner = lane ^ 2
+constexpr int kMirror = 0x1B;  // quad_perm [3,2,1,0]: partner = 3 - lane
+
+// sums / ors over the LPP lanes of a pixel; every lane gets the same bits
+template <int LPP>
+__device__ __forceinline__ float quad_sum(float x)
+{
+    x = x + dpp_f<kSwap1>(x);
+    if constexpr (LPP == 4) x = x + dpp_f<kSwap2>(x);
+    return x;
+}
+template <int LPP>
+__device__ __forceinline__ int quad_sum(int x)
+{
+    x = x + dpp_i<kSwap1>(x);
+    if constexpr (LPP == 4) x = x + dpp_i<kSwap2>(x);
+    return x;
+}
+template <int LPP>
+__device__ __forceinline__ int quad_or(int x)
+{
+    x = x | dpp_i<kSwap1>(x);
+    if constexpr (LPP == 4) x = x | dpp_i<kSwap2>(x);
+    return x;
+}
+
+// in-lane half-cleaners of a bitonic merge: distances NS/2 ... 1, ascending
+template <int NS, int D>
+__device__ __forceinline__ void half_clean(float (&v)[NS])
+{
+    if constexpr (D >= 1) {
+        static_chunks<0, NS / 2, 32>([&](auto T) NL_INL {
+            constexpr int t = decltype(T)::value;
+            constexpr int i = ((t & ~(D - 1)) << 1) | (t & (D - 1));
+            constexpr int l = i | D;
+            const float lo = fminf(v[i], v[l]);
+            const float hi = fmaxf(v[i], v[l]);
+            v[i] = lo;
+            v[l] = hi;
+        });
+        half_clean<NS, (D >> 1)>(v);
+    }
+}
+
+// cross-lane stage against the partner selected by CTRL; MIRROR: element i
+// meets the partner's element NS-1-i (first stage of merging two ascending
+// runs), else element i meets element i (half-cleaner at lane distance)
+template <int NS, int CTRL, bool MIRROR>
+__device__ __forceinline__ void cross_stage(float (&v)[NS], bool keep_min)
+{
+    if constexpr (MIRROR) {
+        static_chunks<0, NS / 2, 16>([&](auto I) NL_INL {
+            constexpr int i = decltype(I)::value;
+            constexpr int j = NS - 1 - i;
+            const float pj = dpp_f<CTRL>(v[j]);
+            const float pi = dpp_f<CTRL>(v[i]);
+            const float a_lo = fminf(v[i], pj), a_hi = fmaxf(v[i], pj);
+            const float b_lo = fminf(v[j], pi), b_hi = fmaxf(v[j], pi);
+            v[i] = keep_min ? a_lo : a_hi;
+            v[j] = keep_min ? b_lo : b_hi;
+        });
+    } else {
+        static_chunks<0, NS, 32>([&](auto I) NL_INL {
+            constexpr int i = decltype(I)::value;
+            const float pv = dpp_f<CTRL>(v[i]);
+            const float lo = fminf(v[i], pv), hi = fmaxf(v[i], pv);
+            v[i] = keep_min ? lo : hi;
+        });
+    }
+}
+
+// value at global sorted rank g (all lanes of the pixel receive it).  TOPW/BOTW
+// restrict the lookup to the last TOPW registers of lane `lo_role` and the first
+// BOTW registers of lane lo_role+1 (the only places g can be in the zonal
+// passes); TOPW = BOTW = NS searches everything.
+template <int LPP, int NS, int TOPW, int BOTW>
+__device__ __forceinline__ float pick_rank(const float (&v)[NS], int g, int role, int lo_role)
+{
+    const int local = g - role * NS;
+    float r = 0.0f;
+    bool hit = false;
+    if constexpr (TOPW >= NS) {
+        hit = (unsigned)local < (unsigned)NS;
+        r = pick<0, NS>(v, local);
+    } else {
+        const bool top = role == lo_role && local >= NS - TOPW && local < NS;
+        const bool bot = role == lo_role + 1 && local >= 0 && local < BOTW;
+        const float rt = pick<NS - TOPW, NS>(v, local);
+        const float rb = pick<0, BOTW>(v, local);
+        hit = top || bot;
+        r = top ? rt : rb;
+    }
+    return __int_as_float(quad_or<LPP>(hit ? __float_as_int(r) : 0));
+}
+
+// ZONAL / generic exactly as in stack_fast.hip; LPP lanes per pixel.
+template <int LPP, bool ZONAL>
+__global__ __launch_bounds__(256) void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
+{
+    constexpr int NS = kMlNS, NT = NS * LPP;
+    constexpr int ZL = kZone;                        // low zone : ranks [0, ZL)           (role 0)
+    constexpr int ZHS = kZone + kPadMax;             // high zone: ranks [NT-ZHS, NT)      (last role)
+    constexpr int ZH = ZONAL ? NT - ZHS : NT;
+    constexpr int LAST = LPP - 1;
+
+    int c_lo_total = 0, c_hi_total = 0;
+    const bool listed = !ZONAL && q.in_list != nullptr;
+    const int64_t limit = listed ? (int64_t)min(*q.in_count, q.in_capacity) : p.npix;
+    const int64_t items_per_wg = blockDim.x / LPP;
+    const int64_t sweep = listed ? (int64_t)gridDim.x * items_per_wg : limit;
+    const int lane = threadIdx.x & 63;
+    const int role = threadIdx.x % LPP;
+
+    for (int64_t wg_item = (int64_t)blockIdx.x * items_per_wg; wg_item < limit; wg_item += sweep) {
+        int N = p.n_frames;
+        asm volatile("" : "+s"(N));
+        const int64_t item = wg_item + threadIdx.x / LPP;
+        const bool on = item < limit;
+        int64_t pix = item;
+        if (listed) pix = on ? (int64_t)q.in_list[item] : 0;
+
+        // ---- gather: lane role r takes frames [r*NS, r*NS+NS); positions past the
+        // last frame re-read it and are turned into missing samples ----
+        float v[NS];
+        int nan_cnt = 0;
+        {
+            const int f0 = role * NS;
+            const int64_t frame_bytes = p.stride * (int64_t)sizeof(float);
+            const int fstart = f0 < N ? f0 : N - 1;
+            const char *fk = reinterpret_cast<const char *>(p.frames) + (int64_t)fstart * frame_bytes +
+                             (int64_t)(on ? pix : 0) * 4;
+            static_chunks<0, NS, 16>([&](auto K) NL_INL {
+                constexpr int k = decltype(K)::value;
+                v[k] = *reinterpret_cast<const float *>(fk);
+                fk += (f0 + k + 1 < N) ? frame_bytes : 0;
+            });
+            static_chunks<0, NS, 16>([&](auto K) NL_INL {
+                constexpr int k = decltype(K)::value;
+                float x = v[k];
+                x = (f0 + k < N) ? x : __builtin_nanf("");
+                nan_cnt += (x != x) ? 1 : 0;
+                v[k] = fminf(x, __builtin_inff());
+            });
+        }
+        sort_network<NS>(v);
+        // ---- merge the LPP sorted runs: lane r ends up with ranks [r*NS, r*NS+NS) ----
+        cross_stage<NS, kSwap1, true>(v, (role & 1) == 0);
+        half_clean<NS, NS / 2>(v);
+        if constexpr (LPP == 4) {
+            cross_stage<NS, kMirror, true>(v, role < 2);
+            cross_stage<NS, kSwap1, false>(v, (role & 1) == 0);
+            half_clean<NS, NS / 2>(v);
+        }
+        const int n = quad_sum<LPP>(NS - nan_cnt);
+
+        bool to_exact = false;
+        float res = p.ref_loc;
+        int c_lo = 0, c_hi = 0;
+        int a = 0, b = n;                       // survivors = global sorted ranks [a, b)
+        bool active = on && n > 0;
+        bool to_generic = false;
+        if constexpr (ZONAL) {
+            to_generic = active && !(n > ZH);
+            active = active && !to_generic;
+        }
+
+        // median windows of the zonal passes: a in [0,ZL), b in (ZH,NT] => the two
+        // middle ranks lie in [NT/2 - ZHS/2 - 1, NT/2 + ZL/2], i.e. at the top of
+        // lane LPP/2-1 and at the bottom of lane LPP/2
+        constexpr int TOPW = ZONAL ? ZHS / 2 + 2 : NS, BOTW = ZONAL ? ZL / 2 + 2 : NS;
+        constexpr int MIDR = LPP / 2 - 1;
+        const float c = pick_rank<LPP, NS, TOPW, BOTW>(v, a + ((b - a) >> 1), role, MIDR);
+
+        // shifted moments of the never-clipped ranks [ZL, ZH), once
+        float d_mid = 0.0f, q_mid = 0.0f;
+        if constexpr (ZONAL) {
+            float d0 = 0, d1 = 0, q0 = 0, q1 = 0;          // [0,ZL), [NS-ZHS,NS) of this lane
+            static_range<0, ZL>([&](auto K) NL_INL {
+                constexpr int k = decltype(K)::value;
+                const float e = v[k] - c;
+                d0 += e; q0 = __builtin_fmaf(e, e, q0);
+            });
+            static_range<NS - ZHS, NS>([&](auto K) NL_INL {
+                constexpr int k = decltype(K)::value;
+                const float e = v[k] - c;
+                d1 += e; q1 = __builtin_fmaf(e, e, q1);
+            });
+            float m0 = 0, m1 = 0, m2 = 0, m3 = 0, r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            static_chunks<0, (NS - ZHS - ZL) / 4, 4>([&](auto K) NL_INL {
+                constexpr int k = ZL + 4 * decltype(K)::value;
+                const float e0 = v[k] - c, e1 = v[k + 1] - c, e2 = v[k + 2] - c, e3 = v[k + 3] - c;
+                m0 += e0; m1 += e1; m2 += e2; m3 += e3;
+                r0 = __builtin_fmaf(e0, e0, r0); r1 = __builtin_fmaf(e1, e1, r1);
+                r2 = __builtin_fmaf(e2, e2, r2); r3 = __builtin_fmaf(e3, e3, r3);
+            });
+            // the low zone of lane 0 and the high zone of the last lane are re-summed per pass
+            float dl = (m0 + m1) + (m2 + m3), ql = (r0 + r1) + (r2 + r3);
+            dl += (role == 0 ? 0.0f : d0) + (role == LAST ? 0.0f : d1);
+            ql += (role == 0 ? 0.0f : q0) + (role == LAST ? 0.0f : q1);
+            d_mid = quad_sum<LPP>(dl);
+            q_mid = quad_sum<LPP>(ql);
+        }
+
+        float amax;
+        {
+            const float lowest = __int_as_float(quad_or<LPP>(role == 0 ? __float_as_int(v[0]) : 0));
+            const float highest = pick_rank<LPP, NS, ZONAL ? ZHS : NS, 1>(v, n - 1, role, ZONAL ? LAST : -2);
+            amax = fmaxf(fabsf(lowest), fabsf(highest));
+        }
+
+        while (__any(active)) {
+            const int cnt = b - a;
+            const float fcnt = (float)cnt;
+            float dz = 0.0f, qz = 0.0f;
+            if constexpr (ZONAL) {
+                float dz0 = 0, qz0 = 0, dz1 = 0, qz1 = 0;
+                static_range<0, ZL>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    const float e = (k >= a) ? v[k] - c : 0.0f;
+                    dz0 += e;
+                    qz0 = __builtin_fmaf(e, e, qz0);
+                });
+                const int b_local = b - LAST * NS;
+                static_range<NS - ZHS, NS>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    const float e = (k < b_local) ? v[k] - c : 0.0f;
+                    dz1 += e;
+                    qz1 = __builtin_fmaf(e, e, qz1);
+                });
+                dz = quad_sum<LPP>((role == 0 ? dz0 : 0.0f) + (role == LAST ? dz1 : 0.0f));
+                qz = quad_sum<LPP>((role == 0 ? qz0 : 0.0f) + (role == LAST ? qz1 : 0.0f));
+            } else {
+                const int a1 = opaque(a - role * NS);
+                float d0 = 0, d1 = 0, d2 = 0, d3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+                static_chunks<0, NS / 4, 2>([&](auto K) NL_INL {
+                    constexpr int k = 4 * decltype(K)::value;
+                    const bool i0 = (unsigned)(k + 0 - a1) < (unsigned)cnt;
+                    const bool i1 = (unsigned)(k + 1 - a1) < (unsigned)cnt;
+                    const bool i2 = (unsigned)(k + 2 - a1) < (unsigned)cnt;
+                    const bool i3 = (unsigned)(k + 3 - a1) < (unsigned)cnt;
+                    const float e0 = i0 ? v[k + 0] - c : 0.0f, e1 = i1 ? v[k + 1] - c : 0.0f;
+                    const float e2 = i2 ? v[k + 2] - c : 0.0f, e3 = i3 ? v[k + 3] - c : 0.0f;
+                    d0 += e0; d1 += e1; d2 += e2; d3 += e3;
+                    q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
+                    q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
+                });
+                dz = quad_sum<LPP>((d0 + d1) + (d2 + d3));
+                qz = quad_sum<LPP>((q0 + q1) + (q2 + q3));
+            }
+            const float dsum = d_mid + dz;
+            const float qsum = q_mid + qz;
+            const float delta = dsum / fcnt;             // mean~ - c
+            const float m = c + delta;
+            const float aa = qsum / fcnt;                // E[(x-c)^2]~
+            const float bb = delta * delta;
+            const float var = fmaxf(aa - bb, 0.0f);
+
+            // ---- bracket the reference's stddev ----
+            // ours: every term carries <= NS/4 + log-depth quad adds + margin roundings
+            const float err_o = ((float)(NS / 4 + 32)) * kU * (aa + bb);
+            const float eps_r = 1.02f * (fcnt + 8.0f) * kU;
+            const float e_m = 1.02f * (fcnt + 2.0f) * kU * amax;
+            const float v_up = var + err_o;
+            const float v_dn = fmaxf(var - err_o, 0.0f);
+            const float v_hi = v_up + v_up * eps_r + e_m * e_m;
+            const float v_lo = fmaxf(v_dn - v_dn * eps_r, 0.0f);
+            const float s_max = __fsqrt_rn(v_hi) * (1.0f + 4.0f * kU);
+            const float s_min = __fsqrt_rn(v_lo) * (1.0f - 4.0f * kU);
+            bool bail = !(v_hi < 3.0e38f);
+
+            // ---- exact median (qsort.go:68-82) ----
+            const int kk = a + (cnt >> 1);
+            const float upper = pick_rank<LPP, NS, TOPW, BOTW>(v, kk, role, MIDR);
+            const float lower = pick_rank<LPP, NS, TOPW, BOTW>(v, kk - 1, role, MIDR);
+            const float median = (cnt & 1) ? upper : 0.5f * (lower + upper);
+
+            // ---- the reference's bound expressions (stack.go:408-409) at both ends ----
+            const float tl0 = __fmul_rn(p.sig_lo, s_min), tl1 = __fmul_rn(p.sig_lo, s_max);
+            const float th0 = __fmul_rn(p.sig_hi, s_min), th1 = __fmul_rn(p.sig_hi, s_max);
+            const float la = __fsub_rn(median, tl0), lb = __fsub_rn(median, tl1);
+            const float ha = __fadd_rn(median, th0), hb = __fadd_rn(median, th1);
+            const float lo_min = fminf(la, lb), lo_max = fmaxf(la, lb);
+            const float hi_min = fminf(ha, hb), hi_max = fmaxf(ha, hb);
+
+            // ---- certain (c1,d1) and possible (c2,d2) clips: sorted => prefix / suffix ----
+            int c1 = 0, c2 = 0, d1 = 0, d2 = 0;
+            if constexpr (ZONAL) {
+                static_range<0, ZL>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    c1 += (v[k] < lo_min) ? 1 : 0;
+                    c2 += (v[k] < lo_max) ? 1 : 0;
+                });
+                static_range<NS - ZHS, NS>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    d1 += (v[k] > hi_max) ? 1 : 0;
+                    d2 += (v[k] > hi_min) ? 1 : 0;
+                });
+                c1 = quad_sum<LPP>(role == 0 ? c1 : 0); c2 = quad_sum<LPP>(role == 0 ? c2 : 0);
+                d1 = quad_sum<LPP>(role == LAST ? d1 : 0); d2 = quad_sum<LPP>(role == LAST ? d2 : 0);
+                c1 = max(c1 - a, 0); c2 = max(c2 - a, 0);
+                d1 = max(d1 - (NT - b), 0); d2 = max(d2 - (NT - b), 0);
+                if (active && ((a + c2 >= ZL) || (b - d2 <= ZH))) {
+                    to_generic = true;
+                    active = false;
+                }
+            } else {
+                static_chunks<0, NS, 8>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    const float x = v[k];
+                    c1 += (x < lo_min) ? 1 : 0;
+                    c2 += (x < lo_max) ? 1 : 0;
+                    d1 += (x > hi_max) ? 1 : 0;
+                    d2 += (x > hi_min) ? 1 : 0;
+                });
+                c1 = quad_sum<LPP>(c1); c2 = quad_sum<LPP>(c2);
+                d1 = quad_sum<LPP>(d1); d2 = quad_sum<LPP>(d2);
+                c1 = min(max(c1 - a, 0), cnt); c2 = min(max(c2 - a, 0), cnt);
+                d1 = min(max(d1 - (NT - b), 0), cnt); d2 = min(max(d2 - (NT - b), 0), cnt);
+            }
+            if (active) {
+                bail |= (c1 != c2) || (d1 != d2) || (lo_max > hi_min && (c1 + d1) > 0);
+                if (bail) {
+                    to_exact = true;
+                    active = false;
+                } else {
+                    c_lo += c1;
+                    c_hi += d1;
+                    a += c1;
+                    b -= d1;
+                    amax = fminf(amax, fmaxf(fabsf(lo_min), fabsf(hi_max)));
+                    if ((c1 + d1) == 0 || (b - a) <= 1) {     // stack.go:427-430
+                        res = m;
+                        active = false;
+                    }
+                }
+            }
+        }
+
+        // one lane per pixel reports
+        const bool rep = on && role == 0;
+        if (rep && !to_generic && !to_exact) {
+            p.out[pix] = res;
+            c_lo_total += c_lo;
+            c_hi_total += c_hi;
+        }
+        if constexpr (ZONAL) {
+            const unsigned long long gm = __ballot(rep && to_generic);
+            if (gm) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(q.gen_count, (unsigned)__popcll(gm));
+                base = __shfl(base, 0, 64);
+                const unsigned slot = base + (unsigned)__popcll(gm & ((1ull << lane) - 1ull));
+                if (rep && to_generic && slot < q.gen_capacity) q.gen_list[slot] = (unsigned)pix;
+            }
+        }
+        const unsigned long long em = __ballot(rep && to_exact);
+        if (em) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(q.fb_count, (unsigned)__popcll(em));
+            base = __shfl(base, 0, 64);
+            const unsigned slot = base + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
+            if (rep && to_exact && slot < q.fb_capacity) q.fb_list[slot] = (unsigned)pix;
+        }
+    }
+
+    __shared__ int s_lo[4], s_hi[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c_lo_total += __shfl_xor(c_lo_total, o, 64);
+        c_hi_total += __shfl_xor(c_hi_total, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = c_lo_total; s_hi[threadIdx.x >> 6] = c_hi_total; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t_lo = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3];
+        const int t_hi = s_hi[0] + s_hi[1] + s_hi[2] + s_hi[3];
+        unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+        if (t_lo) atomicAdd(slot + 0, (unsigned long long)t_lo);
+        if (t_hi) atomicAdd(slot + 1, (unsigned long long)t_hi);
+    }
+}
+
+int fast_ml_supported(int mode, bool weighted, int n_frames)
+{
+    return (mode == NL_ST_SIGMA && !weighted && n_frames > 128 && n_frames <= 512) ? 1 : 0;
+}
+
+template <int LPP>
+static void launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
+                      hipEvent_t dominant_done)
+{
+    const unsigned per_wg = 256 / LPP;
+    const unsigned tile_blocks = (unsigned)((args.npix + per_wg - 1) / per_wg);
+    FastArgs f = fargs;
+    f.in_list = nullptr;
+    f.in_count = nullptr;
+    f.in_capacity = 0;
+    hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, true>), dim3(tile_blocks), dim3(256), 0, stream, args, f);
+    if (dominant_done) (void)hipEventRecord(dominant_done, stream);
+    f.in_list = fargs.gen_list;
+    f.in_count = fargs.gen_count;
+    f.in_capacity = fargs.gen_capacity;
+    const unsigned gblocks = tile_blocks < kGenericGrid ? tile_blocks : kGenericGrid;
+    hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, false>), dim3(gblocks), dim3(256), 0, stream, args, f);
+}
+
+hipError_t launch_stack_sigma_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
+                                 const char **name, hipEvent_t dominant_done)
+{
+    if (args.n_frames <= 256) {
+        *name = "stack_sigma_ml_kernel<2>";
+        launch_ml<2>(args, fargs, stream, dominant_done);
+    } else {
+        *name = "stack_sigma_ml_kernel<4>";
+        launch_ml<4>(args, fargs, stream, dominant_done);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace nl

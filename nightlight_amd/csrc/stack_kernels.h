@@ -59,6 +59,15 @@ hipError_t launch_stack_median_fast(const StackArgs &args, hipStream_t stream, c
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, int *blocks_used,
                                    hipStream_t stream, const char **name, hipEvent_t dominant_done);
 
+// ---- stack_fast_ml.hip (129..512 frames, 2 or 4 lanes per pixel) ----
+int fast_ml_supported(int mode, bool weighted, int n_frames);
+hipError_t launch_stack_sigma_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
+                                 const char **name, hipEvent_t dominant_done);
+
+// ---- stack_exact_coop.hip (bit-exact sigma replay, one wave per pixel) ----
+int coop_supported(int mode, bool weighted, int n_frames);
+hipError_t launch_stack_sigma_coop(const StackArgs &args, int grid, hipStream_t stream, const char **name);
+
 // ---- stack_mean.hip ----
 hipError_t launch_stack_mean(bool weighted, const StackArgs &args, hipStream_t stream,
                              const char **name);

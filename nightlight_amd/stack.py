@@ -117,7 +117,7 @@ class StackHandle:
 
     def set_exact(self, on=True):
         """Force the bit-exact kernels (verification); default is the fast path."""
-        capi.check(self._lib.nl_stack_set_exact(self._h, int(bool(on))))
+        capi.check(self._lib.nl_stack_set_exact(self._h, int(on)))
 
     @property
     def last_fallback_pixels(self):

@@ -81,6 +81,34 @@ def test_fast_median_is_bit_exact(nl, oracle, n):
     assert same_values(got, want), "fast median n=%d: %s" % (n, describe_mismatch(got, want))
 
 
+@pytest.mark.parametrize("n", [129, 200, 256, 257, 300, 384, 500, 512])
+@pytest.mark.parametrize("clean", [False, True])
+def test_multi_lane_sigma_129_to_512_frames(nl, oracle, n, clean):
+    # 2 or 4 lanes per pixel (stack_fast_ml.hip): cross-lane merge, quad reductions.
+    # clean=True keeps every wave in the zonal passes (no missing samples)
+    width, height = 67, 9
+    if clean:
+        frames = make_frames(n, width, height, seed=700 + n, nan_frac=0.0, nan_border=False,
+                             all_nan_patch=False)
+    else:
+        frames = make_frames(n, width, height, seed=700 + n, nan_frac=0.01)
+    got, gc, want, wc = run_both(nl, oracle, 2, frames, width, height, None, 3.0, 2.5, exact=False)
+    assert gc == wc, "multi-lane sigma n=%d clip counters %r vs oracle %r" % (n, gc, wc)
+    assert close_values(got, want), "multi-lane sigma n=%d: %s" % (n, describe_mismatch(got, want))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 33, 64, 65, 128, 130, 300, 512])
+def test_wave_per_pixel_exact_replay_is_bit_exact(nl, oracle, n):
+    # stack_exact_coop.hip: 64 lanes replay ONE pixel in the reference's order
+    # (the fallback of the register-resident kernels); forced here for every pixel
+    width, height = 37, 5
+    frames = make_frames(n, width, height, seed=900 + n, ties=(n % 2 == 1))
+    for kappa in (2.75, 1.0):
+        got, gc, want, wc = run_both(nl, oracle, 2, frames, width, height, None, kappa, kappa, exact=2)
+        assert same_values(got, want), "coop n=%d: %s" % (n, describe_mismatch(got, want))
+        assert gc == wc
+
+
 def test_fast_sigma_clean_frames_no_nan(nl, oracle):
     # no missing samples at all: every wave stays in the zonal passes
     width, height, n = 256, 64, 128

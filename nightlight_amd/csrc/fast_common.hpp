@@ -100,24 +100,35 @@ __device__ __forceinline__ void sort_network(float (&v)[NS])
     });
 }
 
-// value at a per-lane position idx, known to lie in [B, E)
-template <int B, int E, int NS>
-__device__ __forceinline__ float pick(const float (&v)[NS], int idx)
-{
-    float r = v[B];
-    static_range<B + 1, E>([&](auto K) NL_INL {
-        constexpr int k = decltype(K)::value;
-        r = (idx == k) ? v[k] : r;
-    });
-    return r;
-}
-
 // the compiler must not share the 'rank in [a,b)' masks between passes: 128
 // live lane masks would spill the SGPR file
 __device__ __forceinline__ int opaque(int x)
 {
     asm volatile("" : "+v"(x));
     return x;
+}
+
+// value at a per-lane position idx, known to lie in [B, E).  The index is
+// re-materialised every 8 candidates so that at most 8 compare masks are live.
+template <int B, int E, int NS>
+__device__ __forceinline__ float pick(const float (&v)[NS], int idx)
+{
+    float r = v[B];
+    static_range<B + 1, E>([&](auto K) NL_INL {
+        constexpr int k = decltype(K)::value;
+        if constexpr (((k - B) & 7) == 0) idx = opaque(idx);
+        r = (idx == k) ? v[k] : r;
+    });
+    return r;
+}
+
+// NaN -> +Inf, everything else unchanged: IEEE minNum(NaN, Inf) = Inf.  Written
+// as the instruction itself so that it stays ONE VALU op without a lane mask.
+__device__ __forceinline__ float nan_to_inf(float x)
+{
+    float y;
+    asm("v_min_f32 %0, %1, %2" : "=v"(y) : "v"(x), "v"(__builtin_inff()));
+    return y;
 }
 
 }  // namespace nl

@@ -2,7 +2,7 @@
 // LPP = 2 or 4 ADJACENT lanes share one pixel, each lane keeps 128 samples in
 // VGPRs (so the register footprint equals the 128-frame kernel's).
 //
-//   * lane role r loads frames [128 r, 128 r + 128) of the pixel;
+//   * lane role r loads frames r, r+LPP, r+2*LPP, ... of the pixel;
 //   * each lane sorts its 128 values with the odd-even merge network;
 //   * the 2 (4) sorted runs are merged across lanes with bitonic merge stages:
 //     the cross-lane compare-exchanges read the partner's register through a
@@ -161,22 +161,42 @@ __global__ __launch_bounds__(256) void stack_sigma_ml_kernel(StackArgs p, FastAr
         float v[NS];
         int nan_cnt = 0;
         {
-            const int f0 = role * NS;
-            const int64_t frame_bytes = p.stride * (int64_t)sizeof(float);
-            const int fstart = f0 < N ? f0 : N - 1;
-            const char *fk = reinterpret_cast<const char *>(p.frames) + (int64_t)fstart * frame_bytes +
-                             (int64_t)(on ? pix : 0) * 4;
+            // Frames are dealt round-robin: lane role r takes frames r, r+LPP, ...
+            // (any split works, the column is sorted afterwards).  Buffer loads:
+            // scalar descriptor per register index k (frames k*LPP .. k*LPP+LPP-1),
+            // per-lane byte offset = pixel + role * frame; indices are clamped to
+            // the last frame and the surplus positions become missing samples.
+            const int frame_bytes = (int)(p.stride * (int64_t)sizeof(float));
+            const int last = N - 1;
+            const int boff = (int)((unsigned)(on ? pix : 0) * 4u);
+            // A per-lane pointer walks the lane's frames (role, role+LPP, ...): it
+            // advances by LPP frames while the next frame exists and then stays on
+            // the lane's last frame (valid address; the surplus positions are
+            // marked missing below).  The step is masked arithmetically -- no
+            // branches, no lane masks -- and the chain keeps register pressure low.
+            const int64_t step = (int64_t)LPP * frame_bytes;
+            const int first = min(role, last);
+            const char *fk = reinterpret_cast<const char *>(p.frames) + (int64_t)first * frame_bytes + boff;
+            // lastr - k*LPP < 0  <=>  frame k*LPP+role does not exist.  lastr is
+            // re-materialised every 8 steps so these per-lane tests are computed
+            // where they are used instead of 128 of them being kept in registers.
+            int lastr = last - role;
             static_chunks<0, NS, 16>([&](auto K) NL_INL {
                 constexpr int k = decltype(K)::value;
+                if constexpr ((k & 7) == 0) lastr = opaque(lastr);
                 v[k] = *reinterpret_cast<const float *>(fk);
-                fk += (f0 + k + 1 < N) ? frame_bytes : 0;
+                const int64_t stop = (int64_t)((lastr - (k + 1) * LPP) >> 31);      // next frame missing: -1
+                fk += step & ~stop;
             });
-            static_chunks<0, NS, 16>([&](auto K) NL_INL {
+            int lastp = opaque(last) - role;
+            static_chunks<0, NS, 8>([&](auto K) NL_INL {
                 constexpr int k = decltype(K)::value;
-                float x = v[k];
-                x = (f0 + k < N) ? x : __builtin_nanf("");
-                nan_cnt += (x != x) ? 1 : 0;
-                v[k] = fminf(x, __builtin_inff());
+                if constexpr ((k & 7) == 0) lastp = opaque(lastp);
+                const int pad = (lastp - k * LPP) >> 31;                           // all ones -> NaN
+                const int bits = __float_as_int(v[k]) | pad;
+                // integer NaN test, kept opaque so the count is not sunk below the sort
+                nan_cnt = opaque(nan_cnt - ((0x7f800000 - (bits & 0x7fffffff)) >> 31));
+                v[k] = nan_to_inf(__int_as_float(bits));
             });
         }
         sort_network<NS>(v);

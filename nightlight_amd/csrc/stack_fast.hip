@@ -36,51 +36,6 @@
 
 namespace nl {
 
-// Gather one pixel's samples into registers and sort them ascending; returns
-// the number of valid samples n (they occupy v[0..n), +Inf above).
-// NaN = no data (stack.go:380-387): NaNs and unused positions (k >= N) become
-// +Inf and sort last.  All loads are issued first (independent, 256 B per wave
-// each); the frame pointer advances by one frame per position and stops at the
-// last frame, so unused positions re-read a valid address.
-template <int NS>
-__device__ __forceinline__ int gather_sorted(const float *frames, int64_t stride, int N,
-                                             unsigned boff, float (&v)[NS])
-{
-    // Buffer loads: the address is (scalar descriptor base) + (scalar offset) +
-    // (one per-lane byte offset), so the 128 loads need neither per-load VGPR
-    // address pairs nor branches.  Four frames share a descriptor; the frame
-    // index is clamped to the last frame (positions k >= N re-read it and are
-    // turned into missing samples below).
-    const int64_t frame_bytes = stride * (int64_t)sizeof(float);
-    const int last = N - 1;
-    static_chunks<0, NS / 4, 4>([&](auto C) NL_INL {
-        constexpr int c0 = 4 * decltype(C)::value;
-        const int f0 = min(c0, last);
-        const char *gb = reinterpret_cast<const char *>(frames) + (int64_t)f0 * frame_bytes;
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gb), 0, -1, 0x00020000);
-        static_range<0, 4>([&](auto U) NL_INL {
-            constexpr int k = c0 + decltype(U)::value;
-            const int soff = (min(k, last) - f0) * (int)frame_bytes;
-            v[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)boff, soff, 0));
-        });
-    });
-    int nan_cnt = 0;
-    static_chunks<0, NS, 8>([&](auto K) NL_INL {
-        constexpr int k = decltype(K)::value;
-        const int pad = (N - 1 - k) >> 31;
-        const int bits = __float_as_int(v[k]) | pad;
-        // NaN <=> (bits & 0x7fffffff) > 0x7f800000; counted with integer
-        // arithmetic (a compare would park a lane mask in SGPRs per element)
-        // (kept opaque: otherwise the compiler sinks the whole count below the sort
-        // and parks one lane mask per element in SGPRs until then)
-        nan_cnt = opaque(nan_cnt - ((0x7f800000 - (bits & 0x7fffffff)) >> 31));
-        v[k] = nan_to_inf(__int_as_float(bits));
-    });
-    sort_network<NS>(v);
-    return NS - nan_cnt;
-}
-
 // StackMedian (stack.go:274-303): the median is order independent, so the
 // sorted register column gives it exactly (qsort.go:68-82: odd n -> middle,
 // even n -> 0.5*(lower+upper)).  Bit-exact, no hand-over lists.

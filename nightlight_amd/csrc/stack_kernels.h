@@ -68,6 +68,11 @@ hipError_t launch_stack_sigma_ml(const StackArgs &args, const FastArgs &fargs, h
 int coop_supported(int mode, bool weighted, int n_frames);
 hipError_t launch_stack_sigma_coop(const StackArgs &args, int grid, hipStream_t stream, const char **name);
 
+// ---- stack_linfit.hip (register-resident linear fit, bit-exact) ----
+int linfit_fast_supported(int mode, int n_frames);
+hipError_t launch_stack_linfit_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
+                                    const char **name);
+
 // ---- stack_mean.hip ----
 hipError_t launch_stack_mean(bool weighted, const StackArgs &args, hipStream_t stream,
                              const char **name);

@@ -1,0 +1,236 @@
+// stack_linfit.hip -- register-resident StackLinearFit for gfx950, BIT-EXACT.
+//
+// Reference: internal/ops/stack/stack.go:834-918, internal/stats/stats.go:569-586.
+// Every iteration of the reference sorts the surviving samples and then sums
+// over them IN SORTED ORDER (MeanStdDev of the ys, the correlation sum, the
+// mean absolute deviation).  A sorted sequence is unique, and removing the
+// rejected samples from a sorted sequence leaves it sorted, so:
+//   * one sorting network at the start replaces every QSortFloat32 call;
+//   * the rejected samples are just marked dead in a per-pixel bit mask and
+//     skipped (their term is multiplied by 0.0f, which leaves the sum unchanged);
+//   * each sum is accumulated sequentially in register order = sorted order,
+//     with the reference's own fp32 operations (never fused), so every
+//     intermediate -- slope, intercept, sigma, the reject decisions, the
+//     counters and the result -- is bit-identical to the reference.
+// One pixel per lane, samples in VGPRs, no LDS, no hand-over lists (a pixel
+// with a +-Inf sample is replayed by the LDS kernel: its pads are +Inf too).
+// MeanStdDev of xs = 0..m-1 depends on m only and comes from the host table.
+#include "fast_common.hpp"
+
+namespace nl {
+
+__device__ __forceinline__ float sqrt_go(float x)      // float32(math.Sqrt(float64(x))), stats.go:259
+{
+    return (float)__builtin_sqrt((double)x);
+}
+
+// These make the compiler forget what it knows about a value (no instruction is
+// emitted).  Used between the passes of an iteration: otherwise it keeps the
+// 128 per-sample liveness factors and the 128 differences x-ymean of one pass
+// in registers for the next pass instead of recomputing them (2-3x the VGPRs).
+__device__ __forceinline__ float opaque_f(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ unsigned opaque_u(unsigned x) { asm volatile("" : "+v"(x)); return x; }
+template <int NW>
+__device__ __forceinline__ void forget_words(unsigned (&w)[NW])
+{
+    static_assert(NW <= 4, "at most 128 samples");
+    asm volatile("" : "+v"(w[0]));
+    if constexpr (NW > 1) asm volatile("" : "+v"(w[1]));
+    if constexpr (NW > 2) asm volatile("" : "+v"(w[2]));
+    if constexpr (NW > 3) asm volatile("" : "+v"(w[3]));
+}
+
+// 1 if x < 0 (sign bit), else 0 -- integer arithmetic on purpose: a compare
+// would produce a lane mask in SGPRs per element
+__device__ __forceinline__ unsigned sign_bit(float x) { return (unsigned)__float_as_int(x) >> 31; }
+
+template <int NS>
+__global__ __launch_bounds__(256) void stack_linfit_fast_kernel(StackArgs p, FastArgs q)
+{
+    constexpr int NW = (NS + 31) / 32;          // liveness words per pixel
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = pix < p.npix;
+    const int lane = threadIdx.x & 63;
+    const unsigned boff = (unsigned)(on ? pix : 0) * 4u;
+    float v[NS];
+    const int n = gather_sorted<NS>(p.frames, p.stride, p.n_frames, boff, v);
+
+    // The sorted column never changes; a sample's liveness is one bit of
+    // live[].  Initially the n valid samples (positions 0..n-1) are alive.
+    // Pads are +Inf: replaced by 0 so that dead positions stay finite (they are
+    // multiplied by 0.0f below).  A genuine +-Inf sample cannot be told from a
+    // pad afterwards -> exact kernel.
+    unsigned live[NW];
+    static_range<0, NW>([&](auto W) NL_INL {
+        constexpr int w = decltype(W)::value;
+        const int c = min(max(n - 32 * w, 0), 32);
+        live[w] = c >= 32 ? 0xFFFFFFFFu : ((1u << c) - 1u);
+    });
+    unsigned inf_any = 0;
+    {
+        int nn = n;
+        static_chunks<0, NS, 8>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            if constexpr ((k & 7) == 0) nn = opaque(nn);
+            const unsigned pad = (unsigned)((nn - 1 - k) >> 31);                // all ones for k >= n
+            const unsigned bits = (unsigned)__float_as_int(v[k]);
+            inf_any |= (((bits & 0x7fffffffu) == 0x7f800000u) ? 1u : 0u) & ~pad;
+            v[k] = __int_as_float((int)(bits & ~pad));                       // pads -> +0.0f
+        });
+    }
+    const bool to_exact = inf_any != 0;
+
+    float res = p.ref_loc;
+    int c_lo = 0, c_hi = 0;
+    int m = n;                                  // surviving samples
+    bool active = on && n > 0 && !to_exact;
+
+    while (__any(active)) {
+        const float fm = (float)m;
+        const int mt = (active && m >= 1) ? m : 1;
+        const float xm = p.xstat[2 * mt], xsd = p.xstat[2 * mt + 1];
+        // liveness of position k as 0.0f / 1.0f:  x * lf  is x or +-0, exactly
+#define NL_LF(k) ((float)((live[(k) >> 5] >> ((k) & 31)) & 1u))
+        // ---- MeanStdDev(ys), stats.go:246-261, sequential in sorted order ----
+        float s = 0.0f;
+        static_chunks<0, NS, 16>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            s = __fadd_rn(s, __fmul_rn(v[k], NL_LF(k)));
+        });
+        const float ym = s / fm;
+        float vs = 0.0f;
+        forget_words<NW>(live);
+        static_chunks<0, NS, 16>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            const float d = __fsub_rn(v[k], ym);
+            const float dd = __fmul_rn(d, d);
+            vs = __fadd_rn(vs, __fmul_rn(dd, NL_LF(k)));
+        });
+        const float ysd = sqrt_go(vs / fm);
+        // ---- correlation, stats.go:573-579 (divisor n+1, quirk Q5) ----
+        float corr = 0.0f, fi = 0.0f;
+        forget_words<NW>(live);
+        const float ym2 = opaque_f(ym);
+        static_chunks<0, NS, 16>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            const float lf = NL_LF(k);
+            const float dx = __fsub_rn(fi, xm);
+            const float dy = __fsub_rn(v[k], ym2);
+            const float t = __fmul_rn(dx, dy);
+            corr = __fadd_rn(corr, __fmul_rn(t, lf));
+            fi += lf;                                            // index among the survivors
+        });
+        float den = __fmul_rn(xsd, ysd);
+        den = __fmul_rn(den, __fadd_rn(fm, 1.0f));
+        corr = corr / den;
+        float slope = __fmul_rn(corr, ysd);
+        slope = slope / xsd;
+        float icpt = __fsub_rn(ym, __fmul_rn(slope, xm));
+        // ---- mean absolute deviation from the fit, stack.go:879-886 ----
+        // (a NaN fit -- ystddev 0 -- makes every term NaN in the reference too)
+        float sg = 0.0f;
+        fi = 0.0f;
+        forget_words<NW>(live);
+        static_chunks<0, NS, 16>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            const float lf = NL_LF(k);
+            const float lin = __fadd_rn(__fmul_rn(fi, slope), icpt);
+            const float diff = __fsub_rn(v[k], lin);
+            sg = __fadd_rn(sg, __fmul_rn(fabsf(diff), lf));
+            fi += lf;
+        });
+        sg = sg / fm;
+        // ---- reject, stack.go:890-904 ----
+        // Reference: lin-g > lb -> low, else g-lin > hb -> high; any NaN in the fit
+        // makes both comparisons false.  Done with sign bits: lb - (lin-g) < 0 <=>
+        // lin-g > lb.  A NaN fit is neutralised first (flat line, infinite bounds).
+        float lb = __fmul_rn(p.sig_lo, sg), hb = __fmul_rn(p.sig_hi, sg);
+        const bool bad = !(slope == slope) || !(icpt == icpt) || !(lb == lb) || !(hb == hb);
+        if (bad) { slope = 0.0f; icpt = 0.0f; lb = __builtin_inff(); hb = __builtin_inff(); }
+        unsigned lo_n = 0, hi_n = 0;
+        unsigned nlive[NW];
+        static_range<0, NW>([&](auto W) NL_INL { nlive[decltype(W)::value] = live[decltype(W)::value]; });
+        fi = 0.0f;
+        forget_words<NW>(live);
+        slope = opaque_f(slope);
+        static_chunks<0, NS, 16>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            const unsigned lbit = (live[k >> 5] >> (k & 31)) & 1u;
+            const float g = v[k];
+            const float lin = __fadd_rn(__fmul_rn(fi, slope), icpt);
+            const unsigned low = sign_bit(__fsub_rn(lb, __fsub_rn(lin, g))) & lbit;
+            const unsigned high = sign_bit(__fsub_rn(hb, __fsub_rn(g, lin))) & lbit & ~low;
+            // (opaque: integer sums may be re-associated, and the compiler would
+            // first compute the bits of all samples and only then add them up)
+            lo_n = opaque_u(lo_n + low);
+            hi_n = opaque_u(hi_n + high);
+            nlive[k >> 5] = opaque_u(nlive[k >> 5] & ~((low | high) << (k & 31)));
+            fi += (float)lbit;
+        });
+#undef NL_LF
+        if (active) {
+            c_lo += (int)lo_n;
+            c_hi += (int)hi_n;
+            const int left = (int)(lo_n + hi_n);
+            res = ym;                                       // stack.go:911: mean of the last regression
+            if (left == 0 || m < 3) active = false;
+            m -= left;
+            static_range<0, NW>([&](auto W) NL_INL { live[decltype(W)::value] = nlive[decltype(W)::value]; });
+        }
+    }
+
+    if (on && !to_exact) p.out[pix] = res;
+    if (!on || to_exact) { c_lo = 0; c_hi = 0; }
+    const unsigned long long em = __ballot(on && to_exact);
+    if (em) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(q.fb_count, (unsigned)__popcll(em));
+        base = __shfl(base, 0, 64);
+        const unsigned slot = base + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
+        if (on && to_exact && slot < q.fb_capacity) q.fb_list[slot] = (unsigned)pix;
+    }
+
+    __shared__ int s_lo[4], s_hi[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c_lo += __shfl_xor(c_lo, o, 64);
+        c_hi += __shfl_xor(c_hi, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = c_lo; s_hi[threadIdx.x >> 6] = c_hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t_lo = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3];
+        const int t_hi = s_hi[0] + s_hi[1] + s_hi[2] + s_hi[3];
+        unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+        if (t_lo) atomicAdd(slot + 0, (unsigned long long)t_lo);
+        if (t_hi) atomicAdd(slot + 1, (unsigned long long)t_hi);
+    }
+}
+
+int linfit_fast_supported(int mode, int n_frames)
+{
+    return (mode == NL_ST_LINEAR_FIT && n_frames >= 1 && n_frames <= 128) ? 1 : 0;
+}
+
+template <int NS>
+static void launch_lf(const StackArgs &args, const FastArgs &f, unsigned blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(stack_linfit_fast_kernel<NS>, dim3(blocks), dim3(256), 0, stream, args, f);
+}
+
+hipError_t launch_stack_linfit_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
+                                    const char **name)
+{
+    const unsigned blocks = (unsigned)((args.npix + 255) / 256);
+    const int n = args.n_frames;
+    if (n <= 8)        { *name = "stack_linfit_fast_kernel<8>";   launch_lf<8>(args, fargs, blocks, stream); }
+    else if (n <= 16)  { *name = "stack_linfit_fast_kernel<16>";  launch_lf<16>(args, fargs, blocks, stream); }
+    else if (n <= 32)  { *name = "stack_linfit_fast_kernel<32>";  launch_lf<32>(args, fargs, blocks, stream); }
+    else if (n <= 48)  { *name = "stack_linfit_fast_kernel<48>";  launch_lf<48>(args, fargs, blocks, stream); }
+    else if (n <= 64)  { *name = "stack_linfit_fast_kernel<64>";  launch_lf<64>(args, fargs, blocks, stream); }
+    else if (n <= 96)  { *name = "stack_linfit_fast_kernel<96>";  launch_lf<96>(args, fargs, blocks, stream); }
+    else               { *name = "stack_linfit_fast_kernel<128>"; launch_lf<128>(args, fargs, blocks, stream); }
+    return hipGetLastError();
+}
+
+}  // namespace nl

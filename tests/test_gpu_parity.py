@@ -109,6 +109,22 @@ def test_wave_per_pixel_exact_replay_is_bit_exact(nl, oracle, n):
         assert gc == wc
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 9, 25, 31, 33, 64, 65, 100, 128])
+def test_register_resident_linear_fit_is_bit_exact(nl, oracle, n):
+    # default dispatch for linear fit (stack_linfit.hip): one sort, then every sum
+    # of stack.go:869-911 runs sequentially in sorted order -> bit-exact
+    width, height = 70, 11
+    frames = make_frames(n, width, height, seed=600 + n, ties=(n % 4 == 1))
+    if n > 3:
+        frames[1, 3] = np.inf            # pixels with infinite samples go to the LDS kernel
+        frames[2, 40] = -np.inf
+    frames[:, 17] = 1234.5               # zero variance: NaN slope, no rejection
+    for sl, sh in ((2.75, 2.75), (1.0, 3.0)):
+        got, gc, want, wc = run_both(nl, oracle, 5, frames, width, height, None, sl, sh, exact=False)
+        assert same_values(got, want), "linear fit n=%d: %s" % (n, describe_mismatch(got, want))
+        assert gc == wc, "linear fit n=%d clip counters %r vs oracle %r" % (n, gc, wc)
+
+
 def test_fast_sigma_clean_frames_no_nan(nl, oracle):
     # no missing samples at all: every wave stays in the zonal passes
     width, height, n = 256, 64, 128

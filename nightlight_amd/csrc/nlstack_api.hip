@@ -389,7 +389,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         f.in_capacity = 0;
         int fast_grid = 0;
         if (a.n_frames <= 128)
-            NL_HIP(nl::launch_stack_sigma_fast(a, f, &fast_grid, h->stream, &h->last_kernel, h->ev_dom1));
+            NL_HIP(nl::launch_stack_sigma_fast(a, f, &fast_grid, h->stream, &h->last_kernel, h->ev_dom1,
+                                               mode == NL_ST_WINSOR_SIGMA));
         else   // 129..512 frames: 2 or 4 lanes per pixel
             NL_HIP(nl::launch_stack_sigma_ml(a, f, h->stream, &h->last_kernel, h->ev_dom1));
         // exact replay of the undecidable pixels: one wave per pixel where available
@@ -399,7 +400,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         e.list_capacity = (unsigned)h->npix;
         const char *exact_name = "";
         if (nl::coop_supported(mode, weighted, a.n_frames)) {
-            NL_HIP(nl::launch_stack_sigma_coop(e, kCoopGrid, h->stream, &exact_name));
+            NL_HIP(nl::launch_stack_sigma_coop(mode, e, kCoopGrid, h->stream, &exact_name));
         } else {
             int lanes = 0;
             size_t lds = 0;
@@ -415,7 +416,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         // verification: the wave-per-pixel exact replay over the whole tile
         h->last_used_fast = false;
         const int64_t g = a.npix < 65536 ? a.npix : 65536;
-        NL_HIP(nl::launch_stack_sigma_coop(a, (int)g, h->stream, &h->last_kernel));
+        NL_HIP(nl::launch_stack_sigma_coop(mode, a, (int)g, h->stream, &h->last_kernel));
         NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
         NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
         h->last_has_counters = true;

@@ -1,4 +1,4 @@
-// stack_exact_coop.hip -- bit-exact StackSigma replay, one WAVEFRONT per pixel.
+// stack_exact_coop.hip -- bit-exact StackSigma / StackWinsorSigma replay, one WAVEFRONT per pixel.
 //
 // The register-resident kernels hand ~1e-4 of the pixels (a sample inside the
 // few-ulp clip window) to an exact replay.  With so few pixels the
@@ -11,8 +11,11 @@
 //                                  (ballot + find-first-set); swaps are single LDS writes
 //   mean/stddev stats.go:246-261   the fp32 sums stay sequential (v_readlane feeds one add chain);
 //                                  differences and squares are computed 64 at a time
+//   winsorize   stack.go:646-672   the copy is clamped 64 samples at a time (ballot counts `changed`),
+//                                  its mean / stddev are the same sequential sums
 //   clip        stack.go:411-424   swap-with-last, same visiting order, clean stretches skipped 64 at a time
-// The pixel's column lives in LDS as a plain array (n_frames floats per wave).
+// The pixel's column lives in LDS as a plain array (n_frames floats per wave;
+// the winsorized variant keeps its clamped copy in a second one).
 #include "stack_kernels.h"
 
 namespace nl {
@@ -109,9 +112,11 @@ __device__ float coop_select_median(float *a, int n)
 
 }  // namespace
 
+template <bool WINSOR>
 __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
 {
     extern __shared__ float a[];
+    float *wz = a + p.n_frames;                   // winsorized copy (WINSOR only)
     const int lane = threadIdx.x;
     const int N = p.n_frames;
     int64_t limit = p.npix;
@@ -152,7 +157,39 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
                     return d * d;
                 });
                 const float var = vs / fn;
-                const float sd = sqrt_like_go(var);
+                float sd = sqrt_like_go(var);
+                if constexpr (WINSOR) {
+                    // stack.go:646-672: clamp a copy to median -/+ 1.5 sd, sd = 1.134 * stddev(copy),
+                    // until no sample moved or sd changed by <= 0.05 %
+                    for (int base = 0; base < n; base += 64)
+                        if (base + lane < n) wz[base + lane] = a[base + lane];
+                    for (;;) {
+                        const float t = 1.5f * sd;
+                        const float wlo = median - t, whi = median + t;
+                        int changed = 0;
+                        for (int base = 0; base < n; base += 64) {
+                            const int idx = base + lane;
+                            const float x = idx < n ? wz[idx] : median;
+                            const bool below = idx < n && x < wlo;
+                            const bool above = idx < n && !below && x > whi;
+                            if (below) wz[idx] = wlo;
+                            if (above) wz[idx] = whi;
+                            changed += __popcll(__ballot(below || above));
+                        }
+                        lds_fence();
+                        const float ws = seq_sum(n, [&](int i) { return i < n ? wz[i] : 0.0f; });
+                        const float wmean = ws / fn;
+                        const float wvs = seq_sum(n, [&](int i) {
+                            const float d = (i < n ? wz[i] : wmean) - wmean;
+                            return d * d;
+                        });
+                        const float old = sd;
+                        sd = 1.134f * sqrt_like_go(wvs / fn);
+                        const float diff = sd - old;
+                        const float factor = fabsf(diff) / old;
+                        if (changed == 0 || factor <= 0.0005f) break;
+                    }
+                }
                 const float t_lo = p.sig_lo * sd, t_hi = p.sig_hi * sd;
                 const float lo = median - t_lo, hi = median + t_hi;
 
@@ -192,14 +229,22 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
 
 int coop_supported(int mode, bool weighted, int n_frames)
 {
-    return (mode == NL_ST_SIGMA && !weighted && (size_t)n_frames * sizeof(float) <= 64 * 1024) ? 1 : 0;
+    if (weighted) return 0;
+    if (mode == NL_ST_SIGMA) return (size_t)n_frames * sizeof(float) <= 64 * 1024 ? 1 : 0;
+    if (mode == NL_ST_WINSOR_SIGMA) return (size_t)n_frames * 2 * sizeof(float) <= 64 * 1024 ? 1 : 0;
+    return 0;
 }
 
-hipError_t launch_stack_sigma_coop(const StackArgs &args, int grid, hipStream_t stream, const char **name)
+hipError_t launch_stack_sigma_coop(int mode, const StackArgs &args, int grid, hipStream_t stream, const char **name)
 {
-    *name = "stack_sigma_coop_kernel";
-    hipLaunchKernelGGL(stack_sigma_coop_kernel, dim3(grid), dim3(64), (size_t)args.n_frames * sizeof(float),
-                       stream, args);
+    const size_t column = (size_t)args.n_frames * sizeof(float);
+    if (mode == NL_ST_WINSOR_SIGMA) {
+        *name = "stack_winsor_coop_kernel";
+        hipLaunchKernelGGL(stack_sigma_coop_kernel<true>, dim3(grid), dim3(64), 2 * column, stream, args);
+    } else {
+        *name = "stack_sigma_coop_kernel";
+        hipLaunchKernelGGL(stack_sigma_coop_kernel<false>, dim3(grid), dim3(64), column, stream, args);
+    }
     return hipGetLastError();
 }
 

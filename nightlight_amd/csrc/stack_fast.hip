@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void stack_median_fast_kernel(StackArgs p)
 // ZONAL = true : grid covers the tile, lane = pixel blockIdx*256+thread;
 // ZONAL = false: grid-stride over q.in_list (pixels handed over by the zonal
 //                kernel), any number of missing / clipped samples.
-template <int NS, bool ZONAL>
+template <int NS, bool ZONAL, bool WINSOR>
 __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
 {
     static_assert(!ZONAL || NS >= 48, "zonal passes need room between the zones");
@@ -125,6 +125,25 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
             q_mid = (q0 + q1) + (q2 + q3);
         }
 
+        // winsorization (stack.go:646-672) clamps at median -/+ 1.5 sigma: in the zonal
+        // passes only sorted positions outside [WL, WH) are allowed to reach a clamp,
+        // the inner half contributes these fixed sums
+        constexpr int WL = ZONAL ? NS / 4 : 0, WH = ZONAL ? NS - NS / 4 - kPadMax : NS;
+        float d_in = 0.0f, q_in = 0.0f;
+        if constexpr (ZONAL && WINSOR) {
+            static_assert(WL >= ZL && WH <= ZH && (WL - ZL) % 4 == 0 && (WH - WL) % 4 == 0, "winsor zones");
+            float d0 = 0, d1 = 0, d2 = 0, d3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+            static_chunks<0, (WH - WL) / 4, 4>([&](auto K) NL_INL {
+                constexpr int k = WL + 4 * decltype(K)::value;
+                const float e0 = v[k] - c, e1 = v[k + 1] - c, e2 = v[k + 2] - c, e3 = v[k + 3] - c;
+                d0 += e0; d1 += e1; d2 += e2; d3 += e3;
+                q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
+                q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
+            });
+            d_in = (d0 + d1) + (d2 + d3);
+            q_in = (q0 + q1) + (q2 + q3);
+        }
+
         // max|x| over the survivors (only enters the reference-mean error term):
         // first pass from the two ends of the sorted column, afterwards from the
         // bounds every survivor passed
@@ -182,8 +201,8 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
             const float v_dn = fmaxf(var - err_o, 0.0f);
             const float v_hi = v_up + v_up * eps_r + e_m * e_m;
             const float v_lo = fmaxf(v_dn - v_dn * eps_r, 0.0f);
-            const float s_max = __fsqrt_rn(v_hi) * (1.0f + 4.0f * kU);
-            const float s_min = __fsqrt_rn(v_lo) * (1.0f - 4.0f * kU);
+            float s_max = __fsqrt_rn(v_hi) * (1.0f + 4.0f * kU);
+            float s_min = __fsqrt_rn(v_lo) * (1.0f - 4.0f * kU);
             bool bail = !(v_hi < 3.0e38f);          // overflow / NaN (e.g. an Inf sample): exact kernel
 
             // ---- exact median (qsort.go:68-82): sorted column, position lookup ----
@@ -192,6 +211,128 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
             const float upper = pick<W0, W1>(v, kk);
             const float lower = pick<W0, W1>(v, kk - 1);
             const float median = (cnt & 1) ? upper : 0.5f * (lower + upper);
+
+            if constexpr (WINSOR) {
+                // ---- winsorized stddev, stack.go:646-672, as an interval ----
+                // The reference repeats { clamp a copy to median -/+ 1.5*std; std =
+                // 1.134*stddev(copy) } until nothing changed or std moved by <= 0.05 %.
+                // Its std is again an order-dependent fp32 sum, so we carry an interval
+                // [w_lo, w_hi] for it through the loop: the clamp bounds become
+                // intervals and the copy's variance is evaluated at the tightest and at
+                // the loosest clamp of the interval (it is monotone in the clamp).
+                constexpr int PZ = ZONAL ? ZH : 0;
+                const float xmin = pick<0, ZONAL ? ZL : NS>(v, a);
+                const float xmax = pick<PZ, NS>(v, b - 1);
+                float w_lo = s_min, w_hi = s_max;
+                float Lm = -__builtin_inff(), Lp = -__builtin_inff();     // running max of the low bounds
+                float Hm = __builtin_inff(), Hp = __builtin_inff();       // running min of the high bounds
+                float f_lo_hull = __builtin_inff(), f_hi_hull = -__builtin_inff();
+                bool inner = active && !bail;
+                int guard = 0;
+                while (__any(inner)) {
+                    const float tA = __fmul_rn(1.5f, w_lo), tB = __fmul_rn(1.5f, w_hi);
+                    const float lo_m = __fsub_rn(median, tB), lo_p = __fsub_rn(median, tA);   // lo_j in [lo_m, lo_p]
+                    const float hi_m = __fadd_rn(median, tA), hi_p = __fadd_rn(median, tB);   // hi_j in [hi_m, hi_p]
+                    // changed == 0 ?  (smallest / largest value of the copy against the new bounds)
+                    const float wmin_m = fmaxf(xmin, Lm), wmin_p = fmaxf(xmin, Lp);
+                    const float wmax_m = fminf(xmax, Hm), wmax_p = fminf(xmax, Hp);
+                    const bool ch_sure = (wmin_p < lo_m) || (wmax_m > hi_p);
+                    const bool ch_none = (wmin_m >= lo_p) && (wmax_p <= hi_m);
+                    // new effective clamp
+                    Lm = fmaxf(Lm, lo_m); Lp = fmaxf(Lp, lo_p);
+                    Hm = fminf(Hm, hi_m); Hp = fminf(Hp, hi_p);
+                    // variance of clamp(x, Lt, Ht) over the survivors (shifted moments) and its error bound
+                    auto clamped_variance = [&](const float Lt, const float Ht, float &wvar, float &werr) NL_INL {
+                    float d0 = 0, d1 = 0, d2 = 0, d3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+                    if constexpr (ZONAL) {
+                        // only the outer quarters of the sorted column can sit on a clamp
+                        // (checked below); the inner half enters unclamped through d_in / q_in
+                        static_range<0, ZL>([&](auto K) NL_INL {
+                            constexpr int k = decltype(K)::value;
+                            const float e = (k >= a) ? fmaxf(v[k], Lt) - c : 0.0f;
+                            d0 += e; q0 = __builtin_fmaf(e, e, q0);
+                        });
+                        static_chunks<0, (WL - ZL) / 4, 2>([&](auto K) NL_INL {
+                            constexpr int k = ZL + 4 * decltype(K)::value;
+                            const float e0 = fmaxf(v[k], Lt) - c, e1 = fmaxf(v[k + 1], Lt) - c;
+                            const float e2 = fmaxf(v[k + 2], Lt) - c, e3 = fmaxf(v[k + 3], Lt) - c;
+                            d0 += e0; d1 += e1; d2 += e2; d3 += e3;
+                            q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
+                            q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
+                        });
+                        static_chunks<0, (ZH - WH) / 4, 2>([&](auto K) NL_INL {
+                            constexpr int k = WH + 4 * decltype(K)::value;
+                            const float e0 = fminf(v[k], Ht) - c, e1 = fminf(v[k + 1], Ht) - c;
+                            const float e2 = fminf(v[k + 2], Ht) - c, e3 = fminf(v[k + 3], Ht) - c;
+                            d0 += e0; d1 += e1; d2 += e2; d3 += e3;
+                            q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
+                            q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
+                        });
+                        static_range<ZH, NS>([&](auto K) NL_INL {
+                            constexpr int k = decltype(K)::value;
+                            const float e = (k < b) ? fminf(v[k], Ht) - c : 0.0f;
+                            d1 += e; q1 = __builtin_fmaf(e, e, q1);
+                        });
+                        d2 += d_in; q2 += q_in;
+                    } else {
+                        const int a4 = opaque(a);
+                        static_chunks<0, NS / 4, 2>([&](auto K) NL_INL {
+                            constexpr int k = 4 * decltype(K)::value;
+                            const bool i0 = (unsigned)(k + 0 - a4) < (unsigned)cnt;
+                            const bool i1 = (unsigned)(k + 1 - a4) < (unsigned)cnt;
+                            const bool i2 = (unsigned)(k + 2 - a4) < (unsigned)cnt;
+                            const bool i3 = (unsigned)(k + 3 - a4) < (unsigned)cnt;
+                            const float e0 = i0 ? __builtin_amdgcn_fmed3f(v[k + 0], Lt, Ht) - c : 0.0f;
+                            const float e1 = i1 ? __builtin_amdgcn_fmed3f(v[k + 1], Lt, Ht) - c : 0.0f;
+                            const float e2 = i2 ? __builtin_amdgcn_fmed3f(v[k + 2], Lt, Ht) - c : 0.0f;
+                            const float e3 = i3 ? __builtin_amdgcn_fmed3f(v[k + 3], Lt, Ht) - c : 0.0f;
+                            d0 += e0; d1 += e1; d2 += e2; d3 += e3;
+                            q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
+                            q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
+                        });
+                    }
+                    const float wd = ((d0 + d1) + (d2 + d3)) / fcnt;
+                    const float wa = ((q0 + q1) + (q2 + q3)) / fcnt;
+                    const float wb = wd * wd;
+                    wvar = fmaxf(wa - wb, 0.0f);
+                    werr = ((float)(NS / 4 + 28)) * kU * (wa + wb);
+                    };
+                    // Clamping to a narrower range never increases a pairwise distance, so
+                    // the variance is monotone in the clamp: the tightest clamp of the
+                    // interval bounds it from below, the loosest from above.
+                    float var_t, err_t, var_l, err_l;
+                    clamped_variance(Lp, Hm, var_t, err_t);
+                    clamped_variance(Lm, Hp, var_l, err_l);
+                    const float w_up = var_l + err_l;
+                    const float w_dn = fmaxf(var_t - err_t, 0.0f);
+                    const float r_hi = __fsqrt_rn(w_up + w_up * eps_r + e_m * e_m) * (1.0f + 4.0f * kU);
+                    const float r_lo = __fsqrt_rn(fmaxf(w_dn - w_dn * eps_r, 0.0f)) * (1.0f - 4.0f * kU);
+                    const float n_lo_s = __fmul_rn(1.134f, r_lo), n_hi_s = __fmul_rn(1.134f, r_hi);
+                    // factor = |new - old| / old  (stack.go:668) over both intervals
+                    const float dmin = __fsub_rn(n_lo_s, w_hi), dmax = __fsub_rn(n_hi_s, w_lo);
+                    const float amin = (dmin <= 0.0f && dmax >= 0.0f) ? 0.0f : fminf(fabsf(dmin), fabsf(dmax));
+                    const float amx = fmaxf(fabsf(dmin), fabsf(dmax));
+                    const float f_lo = (amin / w_hi) * (1.0f - 4.0f * kU), f_hi = (amx / w_lo) * (1.0f + 4.0f * kU);
+                    const bool stop_sure = f_hi <= 0.0005f;
+                    const bool go_sure = f_lo > 0.0005f;
+                    if (inner) {
+                        w_lo = n_lo_s; w_hi = n_hi_s;
+                        // Where an exit test is undecidable the reference EITHER left the
+                        // loop with a value in [w_lo, w_hi] OR went on; we go on and keep the
+                        // hull of every value it may have left with.  The clip step below
+                        // then has to be unambiguous over that hull (0.05 % wide at worst).
+                        const bool may_stop = !ch_sure || !go_sure;
+                        const bool must_stop = ch_none || stop_sure;         // implies may_stop
+                        if (may_stop) { f_lo_hull = fminf(f_lo_hull, w_lo); f_hi_hull = fmaxf(f_hi_hull, w_hi); }
+                        // zonal: the inner half must be strictly inside every clamp of the interval
+                        const bool shape_ok = !ZONAL || (v[WL] >= Lp && v[WH - 1] <= Hm);
+                        if (!shape_ok || !(w_hi < 3.0e38f) || ++guard > 100) { bail = true; inner = false; }
+                        else if (must_stop) inner = false;
+                    }
+                }
+                s_min = f_lo_hull;
+                s_max = f_hi_hull;
+            }
 
             // ---- the reference's bound expressions at both ends of the interval ----
             // (stack.go:408-409; fp32 multiply then add, never fused)
@@ -309,7 +450,7 @@ int fast_supported(int mode, bool weighted, int n_frames)
 {
     if (n_frames < 2 || n_frames > 128) return 0;
     if (mode == NL_ST_MEDIAN) return 1;
-    return (mode == NL_ST_SIGMA && !weighted) ? 1 : 0;
+    return ((mode == NL_ST_SIGMA || mode == NL_ST_WINSOR_SIGMA) && !weighted) ? 1 : 0;
 }
 
 template <int NS>
@@ -335,7 +476,7 @@ hipError_t launch_stack_median_fast(const StackArgs &args, hipStream_t stream, c
 }
 
 
-template <int NS>
+template <int NS, bool WINSOR>
 static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned tile_blocks,
                         int *blocks_used, hipStream_t stream, hipEvent_t dominant_done)
 {
@@ -344,7 +485,7 @@ static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned t
     f.in_count = nullptr;
     f.in_capacity = 0;
     if constexpr (NS >= 48) {
-        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true>), dim3(tile_blocks), dim3(256), 0,
+        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true, WINSOR>), dim3(tile_blocks), dim3(256), 0,
                            stream, args, f);
         if (dominant_done) (void)hipEventRecord(dominant_done, stream);
         // generic pass over the pixels the zonal waves handed over (its length
@@ -353,11 +494,11 @@ static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned t
         f.in_count = fargs.gen_count;
         f.in_capacity = fargs.gen_capacity;
         const unsigned gblocks = tile_blocks < kGenericGrid ? tile_blocks : kGenericGrid;
-        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false>), dim3(gblocks), dim3(256), 0,
+        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false, WINSOR>), dim3(gblocks), dim3(256), 0,
                            stream, args, f);
     } else {
         // small stacks: generic passes are cheap, run them over the whole tile
-        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false>), dim3(tile_blocks), dim3(256), 0,
+        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false, WINSOR>), dim3(tile_blocks), dim3(256), 0,
                            stream, args, f);
         if (dominant_done) (void)hipEventRecord(dominant_done, stream);
     }
@@ -365,21 +506,22 @@ static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned t
 }
 
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, int *blocks_used,
-                                   hipStream_t stream, const char **name, hipEvent_t dominant_done)
+                                   hipStream_t stream, const char **name, hipEvent_t dominant_done,
+                                   bool winsor)
 {
     const unsigned blocks = (unsigned)((args.npix + 255) / 256);
     const int n = args.n_frames;
     // network sizes: the frame count rounded up to the next instantiated size;
     // unused positions count as missing samples
-    if (n <= 8)        { *name = "stack_sigma_fast_kernel<8>";   launch_pair<8>(args, fargs, blocks, blocks_used, stream, dominant_done); }
-    else if (n <= 16)  { *name = "stack_sigma_fast_kernel<16>";  launch_pair<16>(args, fargs, blocks, blocks_used, stream, dominant_done); }
-    else if (n <= 32)  { *name = "stack_sigma_fast_kernel<32>";  launch_pair<32>(args, fargs, blocks, blocks_used, stream, dominant_done); }
-    else if (n <= 48)  { *name = "stack_sigma_fast_kernel<48>";  launch_pair<48>(args, fargs, blocks, blocks_used, stream, dominant_done); }
-    else if (n <= 64)  { *name = "stack_sigma_fast_kernel<64>";  launch_pair<64>(args, fargs, blocks, blocks_used, stream, dominant_done); }
-    else if (n <= 80)  { *name = "stack_sigma_fast_kernel<80>";  launch_pair<80>(args, fargs, blocks, blocks_used, stream, dominant_done); }
-    else if (n <= 96)  { *name = "stack_sigma_fast_kernel<96>";  launch_pair<96>(args, fargs, blocks, blocks_used, stream, dominant_done); }
-    else if (n <= 112) { *name = "stack_sigma_fast_kernel<112>"; launch_pair<112>(args, fargs, blocks, blocks_used, stream, dominant_done); }
-    else               { *name = "stack_sigma_fast_kernel<128>"; launch_pair<128>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    if (n <= 8)        { *name = winsor ? "stack_winsor_fast_kernel<8>" : "stack_sigma_fast_kernel<8>"; if (winsor) launch_pair<8, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<8, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    else if (n <= 16)  { *name = winsor ? "stack_winsor_fast_kernel<16>" : "stack_sigma_fast_kernel<16>"; if (winsor) launch_pair<16, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<16, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    else if (n <= 32)  { *name = winsor ? "stack_winsor_fast_kernel<32>" : "stack_sigma_fast_kernel<32>"; if (winsor) launch_pair<32, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<32, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    else if (n <= 48)  { *name = winsor ? "stack_winsor_fast_kernel<48>" : "stack_sigma_fast_kernel<48>"; if (winsor) launch_pair<48, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<48, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    else if (n <= 64)  { *name = winsor ? "stack_winsor_fast_kernel<64>" : "stack_sigma_fast_kernel<64>"; if (winsor) launch_pair<64, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<64, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    else if (n <= 80)  { *name = winsor ? "stack_winsor_fast_kernel<80>" : "stack_sigma_fast_kernel<80>"; if (winsor) launch_pair<80, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<80, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    else if (n <= 96)  { *name = winsor ? "stack_winsor_fast_kernel<96>" : "stack_sigma_fast_kernel<96>"; if (winsor) launch_pair<96, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<96, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    else if (n <= 112) { *name = winsor ? "stack_winsor_fast_kernel<112>" : "stack_sigma_fast_kernel<112>"; if (winsor) launch_pair<112, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<112, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    else               { *name = winsor ? "stack_winsor_fast_kernel<128>" : "stack_sigma_fast_kernel<128>"; if (winsor) launch_pair<128, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<128, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
     return hipGetLastError();
 }
 

@@ -57,7 +57,8 @@ int fast_supported(int mode, bool weighted, int n_frames);
 hipError_t launch_stack_median_fast(const StackArgs &args, hipStream_t stream, const char **name);
 // dominant_done (optional) is recorded right after the first, dominant kernel
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, int *blocks_used,
-                                   hipStream_t stream, const char **name, hipEvent_t dominant_done);
+                                   hipStream_t stream, const char **name, hipEvent_t dominant_done,
+                                   bool winsor);
 
 // ---- stack_fast_ml.hip (129..512 frames, 2 or 4 lanes per pixel) ----
 int fast_ml_supported(int mode, bool weighted, int n_frames);
@@ -66,7 +67,7 @@ hipError_t launch_stack_sigma_ml(const StackArgs &args, const FastArgs &fargs, h
 
 // ---- stack_exact_coop.hip (bit-exact sigma replay, one wave per pixel) ----
 int coop_supported(int mode, bool weighted, int n_frames);
-hipError_t launch_stack_sigma_coop(const StackArgs &args, int grid, hipStream_t stream, const char **name);
+hipError_t launch_stack_sigma_coop(int mode, const StackArgs &args, int grid, hipStream_t stream, const char **name);
 
 // ---- stack_linfit.hip (register-resident linear fit, bit-exact) ----
 int linfit_fast_supported(int mode, int n_frames);

@@ -69,6 +69,33 @@ def test_fast_sigma_counts_exact_values_close(nl, oracle, n, kappa):
     assert np.max(np.abs(got[ok] - want[ok]) / np.abs(want[ok])) < 2e-6
 
 
+@pytest.mark.parametrize("n", [2, 3, 5, 8, 9, 15, 16, 25, 33, 48, 50, 64, 65, 80, 100, 112, 127, 128])
+@pytest.mark.parametrize("kappa", [2.75, 1.5])
+def test_fast_winsor_counts_exact_values_close(nl, oracle, n, kappa):
+    # default dispatch for winsorized sigma clipping: the same register-resident
+    # kernel, with the winsorization loop of stack.go:646-672 carried as an interval
+    width, height = 131, 37
+    frames = make_frames(n, width, height, seed=400 + n, ties=(n % 5 == 0))
+    got, gc, want, wc = run_both(nl, oracle, 3, frames, width, height, None, kappa, kappa, exact=False)
+    assert gc == wc, "fast winsor n=%d clip counters %r vs oracle %r" % (n, gc, wc)
+    assert close_values(got, want), "fast winsor n=%d: %s" % (n, describe_mismatch(got, want))
+    ok = ~np.isnan(want) & (want != 0)
+    assert np.max(np.abs(got[ok] - want[ok]) / np.abs(want[ok])) < 2e-6
+
+
+def test_fast_winsor_clean_frames_and_outliers(nl, oracle):
+    # no missing samples (zonal passes only), heavy outliers in a few frames
+    width, height, n = 256, 64, 128
+    frames = make_frames(n, width, height, seed=19, nan_frac=0.0, nan_border=False,
+                         all_nan_patch=False)
+    rng = np.random.default_rng(5)
+    hot = rng.integers(0, width * height, 4000)
+    frames[rng.integers(0, n, 4000), hot] *= 40.0
+    frames[:, 100] = 77.0                 # constant pixel: std 0, 0/0 factor, loop ends on changed == 0
+    got, gc, want, wc = run_both(nl, oracle, 3, frames, width, height, None, 3.0, 2.0, exact=False)
+    assert gc == wc and close_values(got, want)
+
+
 @pytest.mark.parametrize("n", [2, 3, 8, 9, 16, 31, 32, 47, 64, 65, 100, 128])
 def test_fast_median_is_bit_exact(nl, oracle, n):
     # default dispatch for the median: register-resident sorting network; the
@@ -103,10 +130,11 @@ def test_wave_per_pixel_exact_replay_is_bit_exact(nl, oracle, n):
     # (the fallback of the register-resident kernels); forced here for every pixel
     width, height = 37, 5
     frames = make_frames(n, width, height, seed=900 + n, ties=(n % 2 == 1))
-    for kappa in (2.75, 1.0):
-        got, gc, want, wc = run_both(nl, oracle, 2, frames, width, height, None, kappa, kappa, exact=2)
-        assert same_values(got, want), "coop n=%d: %s" % (n, describe_mismatch(got, want))
-        assert gc == wc
+    for mode in (2, 3):                   # sigma, winsorized sigma
+        for kappa in (2.75, 1.0):
+            got, gc, want, wc = run_both(nl, oracle, mode, frames, width, height, None, kappa, kappa, exact=2)
+            assert same_values(got, want), "coop %s n=%d: %s" % (MODES[mode], n, describe_mismatch(got, want))
+            assert gc == wc
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 9, 25, 31, 33, 64, 65, 100, 128])

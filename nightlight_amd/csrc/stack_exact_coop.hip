@@ -239,10 +239,10 @@ hipError_t launch_stack_sigma_coop(int mode, const StackArgs &args, int grid, hi
 {
     const size_t column = (size_t)args.n_frames * sizeof(float);
     if (mode == NL_ST_WINSOR_SIGMA) {
-        *name = "stack_winsor_coop_kernel";
+        *name = "stack_sigma_coop_kernel<true>";
         hipLaunchKernelGGL(stack_sigma_coop_kernel<true>, dim3(grid), dim3(64), 2 * column, stream, args);
     } else {
-        *name = "stack_sigma_coop_kernel";
+        *name = "stack_sigma_coop_kernel<false>";
         hipLaunchKernelGGL(stack_sigma_coop_kernel<false>, dim3(grid), dim3(64), column, stream, args);
     }
     return hipGetLastError();

@@ -26,12 +26,14 @@
 // order (<= ~1e-6 relative).
 //
 // Two instantiations per network size.  ZONAL: valid while every lane of the
-// wave misses at most kPadMax samples and has clipped fewer than kZone samples
-// per side; then only the kZone lowest and kZone+kPadMax highest sorted
+// wave misses at most KP samples and has clipped fewer than KZ samples per side
+// (8 and 8; 4 and 4 for networks below 48); then only the KZ lowest and KZ+KP highest sorted
 // positions can ever be excluded and all other positions are summed without a
 // mask.  A wave that leaves this regime (NaN borders, heavy clipping) puts its
 // pixels on the "generic" list; the GENERIC instantiation re-does those from
 // the list with every position masked by its rank.
+#include <string>
+
 #include "fast_common.hpp"
 
 namespace nl {
@@ -61,9 +63,12 @@ __global__ __launch_bounds__(256) void stack_median_fast_kernel(StackArgs p)
 template <int NS, bool ZONAL, bool WINSOR>
 __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
 {
-    static_assert(!ZONAL || NS >= 48, "zonal passes need room between the zones");
-    constexpr int ZL = kZone;                                 // low zone  = positions [0, ZL)
-    constexpr int ZH = ZONAL ? NS - kZone - kPadMax : NS;     // high zone = positions [ZH, NS)
+    // zone widths: 8 clipped + 8 missing samples per lane for the larger
+    // networks, 4 + 4 for the small ones
+    constexpr int KZ = NS >= 48 ? kZone : 4, KP = NS >= 48 ? kPadMax : 4;
+    static_assert(!ZONAL || NS >= 24, "zonal passes need room between the zones");
+    constexpr int ZL = KZ;                                    // low zone  = positions [0, ZL)
+    constexpr int ZH = ZONAL ? NS - KZ - KP : NS;             // high zone = positions [ZH, NS)
 
     int c_lo_total = 0, c_hi_total = 0;
     // ZONAL, or GENERIC without a list: the grid covers the tile, one pixel per
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         // winsorization (stack.go:646-672) clamps at median -/+ 1.5 sigma: in the zonal
         // passes only sorted positions outside [WL, WH) are allowed to reach a clamp,
         // the inner half contributes these fixed sums
-        constexpr int WL = ZONAL ? NS / 4 : 0, WH = ZONAL ? NS - NS / 4 - kPadMax : NS;
+        constexpr int WL = ZONAL ? (NS / 4 + 3) / 4 * 4 : 0, WH = ZONAL ? NS - WL - KP : NS;
         float d_in = 0.0f, q_in = 0.0f;
         if constexpr (ZONAL && WINSOR) {
             static_assert(WL >= ZL && WH <= ZH && (WL - ZL) % 4 == 0 && (WH - WL) % 4 == 0, "winsor zones");
@@ -227,6 +232,7 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                 float Lm = -__builtin_inff(), Lp = -__builtin_inff();     // running max of the low bounds
                 float Hm = __builtin_inff(), Hp = __builtin_inff();       // running min of the high bounds
                 float f_lo_hull = __builtin_inff(), f_hi_hull = -__builtin_inff();
+                const float inv_cnt = 1.0f / fcnt;
                 bool inner = active && !bail;
                 int guard = 0;
                 while (__any(inner)) {
@@ -291,11 +297,11 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                             q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
                         });
                     }
-                    const float wd = ((d0 + d1) + (d2 + d3)) / fcnt;
-                    const float wa = ((q0 + q1) + (q2 + q3)) / fcnt;
+                    const float wd = ((d0 + d1) + (d2 + d3)) * inv_cnt;      // reciprocal: 2 more roundings,
+                    const float wa = ((q0 + q1) + (q2 + q3)) * inv_cnt;      // covered by werr
                     const float wb = wd * wd;
                     wvar = fmaxf(wa - wb, 0.0f);
-                    werr = ((float)(NS / 4 + 28)) * kU * (wa + wb);
+                    werr = ((float)(NS / 4 + 34)) * kU * (wa + wb);
                     };
                     // Clamping to a narrower range never increases a pairwise distance, so
                     // the variance is monotone in the clamp: the tightest clamp of the
@@ -305,16 +311,19 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                     clamped_variance(Lm, Hp, var_l, err_l);
                     const float w_up = var_l + err_l;
                     const float w_dn = fmaxf(var_t - err_t, 0.0f);
-                    const float r_hi = __fsqrt_rn(w_up + w_up * eps_r + e_m * e_m) * (1.0f + 4.0f * kU);
-                    const float r_lo = __fsqrt_rn(fmaxf(w_dn - w_dn * eps_r, 0.0f)) * (1.0f - 4.0f * kU);
+                    // hardware sqrt (1 ulp, flushes denormals): the 4u margins and the absolute
+                    // term cover it
+                    const float r_hi = __builtin_amdgcn_sqrtf(w_up + w_up * eps_r + e_m * e_m) * (1.0f + 4.0f * kU) + 4.0e-19f;
+                    const float r_lo = __builtin_amdgcn_sqrtf(fmaxf(w_dn - w_dn * eps_r, 0.0f)) * (1.0f - 4.0f * kU);
                     const float n_lo_s = __fmul_rn(1.134f, r_lo), n_hi_s = __fmul_rn(1.134f, r_hi);
-                    // factor = |new - old| / old  (stack.go:668) over both intervals
+                    // factor = |new - old| / old <= 0.0005  (stack.go:668-669) over both intervals,
+                    // without the division: fl(x/y) <= t follows from x <= y*t*(1-4u), and
+                    // fl(x/y) > t from x > y*t*(1+4u)
                     const float dmin = __fsub_rn(n_lo_s, w_hi), dmax = __fsub_rn(n_hi_s, w_lo);
                     const float amin = (dmin <= 0.0f && dmax >= 0.0f) ? 0.0f : fminf(fabsf(dmin), fabsf(dmax));
                     const float amx = fmaxf(fabsf(dmin), fabsf(dmax));
-                    const float f_lo = (amin / w_hi) * (1.0f - 4.0f * kU), f_hi = (amx / w_lo) * (1.0f + 4.0f * kU);
-                    const bool stop_sure = f_hi <= 0.0005f;
-                    const bool go_sure = f_lo > 0.0005f;
+                    const bool stop_sure = w_lo > 0.0f && amx <= w_lo * (0.0005f * (1.0f - 4.0f * kU));
+                    const bool go_sure = amin > w_hi * (0.0005f * (1.0f + 4.0f * kU));
                     if (inner) {
                         w_lo = n_lo_s; w_hi = n_hi_s;
                         // Where an exit test is undecidable the reference EITHER left the
@@ -476,15 +485,28 @@ hipError_t launch_stack_median_fast(const StackArgs &args, hipStream_t stream, c
 }
 
 
+// smallest network size with a zonal instantiation
+constexpr int kZonalMinSize = 24;
+
+// kernel names as rocprofv3 prints them (template arguments: NS, ZONAL, WINSOR)
+template <int NS, bool ZONAL, bool WINSOR>
+static const char *sigma_kernel_name()
+{
+    static const std::string name = std::string("stack_sigma_fast_kernel<") + std::to_string(NS) + ", " +
+                                    (ZONAL ? "true" : "false") + ", " + (WINSOR ? "true" : "false") + ">";
+    return name.c_str();
+}
+
 template <int NS, bool WINSOR>
 static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned tile_blocks,
-                        int *blocks_used, hipStream_t stream, hipEvent_t dominant_done)
+                        hipStream_t stream, const char **name, hipEvent_t dominant_done)
 {
     FastArgs f = fargs;
     f.in_list = nullptr;
     f.in_count = nullptr;
     f.in_capacity = 0;
-    if constexpr (NS >= 48) {
+    if constexpr (NS >= kZonalMinSize) {
+        *name = sigma_kernel_name<NS, true, WINSOR>();
         hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true, WINSOR>), dim3(tile_blocks), dim3(256), 0,
                            stream, args, f);
         if (dominant_done) (void)hipEventRecord(dominant_done, stream);
@@ -498,30 +520,40 @@ static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned t
                            stream, args, f);
     } else {
         // small stacks: generic passes are cheap, run them over the whole tile
+        *name = sigma_kernel_name<NS, false, WINSOR>();
         hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false, WINSOR>), dim3(tile_blocks), dim3(256), 0,
                            stream, args, f);
         if (dominant_done) (void)hipEventRecord(dominant_done, stream);
     }
-    *blocks_used = 0;
+}
+
+template <bool WINSOR>
+static void launch_sized(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name,
+                         hipEvent_t dominant_done)
+{
+    const unsigned blocks = (unsigned)((args.npix + 255) / 256);
+    const int n = args.n_frames;
+    // network sizes: the frame count rounded up to the next instantiated size;
+    // unused positions count as missing samples
+    if (n <= 8)        launch_pair<8, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
+    else if (n <= 16)  launch_pair<16, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
+    else if (n <= 24)  launch_pair<24, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
+    else if (n <= 32)  launch_pair<32, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
+    else if (n <= 48)  launch_pair<48, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
+    else if (n <= 64)  launch_pair<64, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
+    else if (n <= 80)  launch_pair<80, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
+    else if (n <= 96)  launch_pair<96, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
+    else if (n <= 112) launch_pair<112, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
+    else               launch_pair<128, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
 }
 
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, int *blocks_used,
                                    hipStream_t stream, const char **name, hipEvent_t dominant_done,
                                    bool winsor)
 {
-    const unsigned blocks = (unsigned)((args.npix + 255) / 256);
-    const int n = args.n_frames;
-    // network sizes: the frame count rounded up to the next instantiated size;
-    // unused positions count as missing samples
-    if (n <= 8)        { *name = winsor ? "stack_winsor_fast_kernel<8>" : "stack_sigma_fast_kernel<8>"; if (winsor) launch_pair<8, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<8, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
-    else if (n <= 16)  { *name = winsor ? "stack_winsor_fast_kernel<16>" : "stack_sigma_fast_kernel<16>"; if (winsor) launch_pair<16, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<16, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
-    else if (n <= 32)  { *name = winsor ? "stack_winsor_fast_kernel<32>" : "stack_sigma_fast_kernel<32>"; if (winsor) launch_pair<32, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<32, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
-    else if (n <= 48)  { *name = winsor ? "stack_winsor_fast_kernel<48>" : "stack_sigma_fast_kernel<48>"; if (winsor) launch_pair<48, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<48, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
-    else if (n <= 64)  { *name = winsor ? "stack_winsor_fast_kernel<64>" : "stack_sigma_fast_kernel<64>"; if (winsor) launch_pair<64, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<64, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
-    else if (n <= 80)  { *name = winsor ? "stack_winsor_fast_kernel<80>" : "stack_sigma_fast_kernel<80>"; if (winsor) launch_pair<80, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<80, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
-    else if (n <= 96)  { *name = winsor ? "stack_winsor_fast_kernel<96>" : "stack_sigma_fast_kernel<96>"; if (winsor) launch_pair<96, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<96, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
-    else if (n <= 112) { *name = winsor ? "stack_winsor_fast_kernel<112>" : "stack_sigma_fast_kernel<112>"; if (winsor) launch_pair<112, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<112, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
-    else               { *name = winsor ? "stack_winsor_fast_kernel<128>" : "stack_sigma_fast_kernel<128>"; if (winsor) launch_pair<128, true>(args, fargs, blocks, blocks_used, stream, dominant_done); else launch_pair<128, false>(args, fargs, blocks, blocks_used, stream, dominant_done); }
+    *blocks_used = 0;
+    if (winsor) launch_sized<true>(args, fargs, stream, name, dominant_done);
+    else        launch_sized<false>(args, fargs, stream, name, dominant_done);
     return hipGetLastError();
 }
 

@@ -465,10 +465,10 @@ hipError_t launch_stack_sigma_ml(const StackArgs &args, const FastArgs &fargs, h
                                  const char **name, hipEvent_t dominant_done)
 {
     if (args.n_frames <= 256) {
-        *name = "stack_sigma_ml_kernel<2>";
+        *name = "stack_sigma_ml_kernel<2, true>";
         launch_ml<2>(args, fargs, stream, dominant_done);
     } else {
-        *name = "stack_sigma_ml_kernel<4>";
+        *name = "stack_sigma_ml_kernel<4, true>";
         launch_ml<4>(args, fargs, stream, dominant_done);
     }
     return hipGetLastError();

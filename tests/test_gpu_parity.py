@@ -53,7 +53,7 @@ def test_mode_matches_oracle(nl, oracle, mode, n):
         assert gc == wc, "%s n=%d clip counters %r vs oracle %r" % (MODES[mode], n, gc, wc)
 
 
-@pytest.mark.parametrize("n", [2, 3, 5, 8, 9, 15, 16, 25, 33, 48, 50, 64, 65, 80, 100, 112, 127, 128])
+@pytest.mark.parametrize("n", [2, 3, 5, 8, 9, 15, 16, 17, 20, 24, 25, 29, 32, 33, 48, 50, 64, 65, 80, 100, 112, 127, 128])
 @pytest.mark.parametrize("kappa", [2.75, 1.5])
 def test_fast_sigma_counts_exact_values_close(nl, oracle, n, kappa):
     # default dispatch: register-resident sigma kernel (+ generic pass on the NaN
@@ -69,7 +69,7 @@ def test_fast_sigma_counts_exact_values_close(nl, oracle, n, kappa):
     assert np.max(np.abs(got[ok] - want[ok]) / np.abs(want[ok])) < 2e-6
 
 
-@pytest.mark.parametrize("n", [2, 3, 5, 8, 9, 15, 16, 25, 33, 48, 50, 64, 65, 80, 100, 112, 127, 128])
+@pytest.mark.parametrize("n", [2, 3, 5, 8, 9, 15, 16, 17, 20, 24, 25, 29, 32, 33, 48, 50, 64, 65, 80, 100, 112, 127, 128])
 @pytest.mark.parametrize("kappa", [2.75, 1.5])
 def test_fast_winsor_counts_exact_values_close(nl, oracle, n, kappa):
     # default dispatch for winsorized sigma clipping: the same register-resident
@@ -308,6 +308,7 @@ def test_tiles_reassemble_the_whole_image(nl, oracle):
     for row0, rows in ((0, 7), (7, 9), (16, 8)):
         with nl.StackHandle(n, width, height, row0=row0, rows=rows) as st:
             st.upload_frames(frames)
+            st.set_exact(True)
             _, cl, ch = st.run(3, 2.5, 2.5, out=out)
             tl += cl
             th += ch

@@ -137,7 +137,8 @@ __device__ __forceinline__ float nan_to_inf(float x)
 // +Inf and sort last.  All loads are issued first (independent, 256 B per wave
 // each); the frame pointer advances by one frame per position and stops at the
 // last frame, so unused positions re-read a valid address.
-template <int NS>
+// GAP: the caller guarantees N > NS - GAP (distance to its next smaller network size).
+template <int NS, int GAP = 16>
 __device__ __forceinline__ int gather_sorted(const float *frames, int64_t stride, int N,
                                              unsigned boff, float (&v)[NS])
 {
@@ -160,17 +161,34 @@ __device__ __forceinline__ int gather_sorted(const float *frames, int64_t stride
             v[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)boff, soff, 0));
         });
     });
-    int nan_cnt = 0;
-    static_chunks<0, NS, 8>([&](auto K) NL_INL {
+    // unused positions k >= N (N > NS - GAP by the choice of NS) become NaN = missing
+    static_range<(NS > GAP ? NS - GAP : 0), NS>([&](auto K) NL_INL {
         constexpr int k = decltype(K)::value;
-        const int pad = (N - 1 - k) >> 31;
-        const int bits = __float_as_int(v[k]) | pad;
-        // NaN <=> (bits & 0x7fffffff) > 0x7f800000; counted with integer
-        // arithmetic (a compare would park a lane mask in SGPRs per element)
-        // (kept opaque: otherwise the compiler sinks the whole count below the sort
-        // and parks one lane mask per element in SGPRs until then)
-        nan_cnt = opaque(nan_cnt - ((0x7f800000 - (bits & 0x7fffffff)) >> 31));
-        v[k] = nan_to_inf(__int_as_float(bits));
+        const int pad = (N - 1 - k) >> 31;                        // scalar: N is uniform
+        v[k] = __int_as_float(__float_as_int(v[k]) | pad);
+    });
+    // Clean waves (no lane holds a NaN or an infinite sample -- everything but the
+    // aligned frames' borders) skip the NaN count: a plain fp32 sum of the column is
+    // finite iff every sample is.  (A sum that overflows only costs the count.)
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+    static_chunks<0, NS / 4, 8>([&](auto K) NL_INL {
+        constexpr int k = 4 * decltype(K)::value;
+        t0 += v[k]; t1 += v[k + 1]; t2 += v[k + 2]; t3 += v[k + 3];
+    });
+    const float total = (t0 + t1) + (t2 + t3);
+    int nan_cnt = 0;
+    if (__any(!(__builtin_fabsf(total) < __builtin_inff()))) {
+        // NaN <=> (bits & 0x7fffffff) > 0x7f800000; counted with integer arithmetic
+        // (a compare would park a lane mask in SGPRs per element); the column is
+        // only read here
+        static_chunks<0, NS, 8>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            nan_cnt = opaque(nan_cnt - ((0x7f800000 - (__float_as_int(v[k]) & 0x7fffffff)) >> 31));
+        });
+    }
+    static_chunks<0, NS, 16>([&](auto K) NL_INL {
+        constexpr int k = decltype(K)::value;
+        v[k] = nan_to_inf(v[k]);
     });
     sort_network<NS>(v);
     return NS - nan_cnt;

@@ -85,23 +85,23 @@ __device__ __forceinline__ void half_clean(float (&v)[NS])
 template <int NS, int CTRL, bool MIRROR>
 __device__ __forceinline__ void cross_stage(float (&v)[NS], bool keep_min)
 {
+    // min(x, y) = med3(x, y, -Inf), max(x, y) = med3(x, y, +Inf): one VALU op per
+    // element whichever side of the exchange the lane is on (no NaN can occur here)
+    const float side = keep_min ? -__builtin_inff() : __builtin_inff();
     if constexpr (MIRROR) {
         static_chunks<0, NS / 2, 16>([&](auto I) NL_INL {
             constexpr int i = decltype(I)::value;
             constexpr int j = NS - 1 - i;
             const float pj = dpp_f<CTRL>(v[j]);
             const float pi = dpp_f<CTRL>(v[i]);
-            const float a_lo = fminf(v[i], pj), a_hi = fmaxf(v[i], pj);
-            const float b_lo = fminf(v[j], pi), b_hi = fmaxf(v[j], pi);
-            v[i] = keep_min ? a_lo : a_hi;
-            v[j] = keep_min ? b_lo : b_hi;
+            v[i] = __builtin_amdgcn_fmed3f(v[i], pj, side);
+            v[j] = __builtin_amdgcn_fmed3f(v[j], pi, side);
         });
     } else {
         static_chunks<0, NS, 32>([&](auto I) NL_INL {
             constexpr int i = decltype(I)::value;
             const float pv = dpp_f<CTRL>(v[i]);
-            const float lo = fminf(v[i], pv), hi = fmaxf(v[i], pv);
-            v[i] = keep_min ? lo : hi;
+            v[i] = __builtin_amdgcn_fmed3f(v[i], pv, side);
         });
     }
 }
@@ -188,15 +188,31 @@ __global__ __launch_bounds__(256) void stack_sigma_ml_kernel(StackArgs p, FastAr
                 const int64_t stop = (int64_t)((lastr - (k + 1) * LPP) >> 31);      // next frame missing: -1
                 fk += step & ~stop;
             });
+            // surplus positions (frame k*LPP+role does not exist) become NaN = missing;
+            // only the last positions can be surplus: N > (LPP-1)*NS by the choice of LPP
             int lastp = opaque(last) - role;
             static_chunks<0, NS, 8>([&](auto K) NL_INL {
                 constexpr int k = decltype(K)::value;
                 if constexpr ((k & 7) == 0) lastp = opaque(lastp);
                 const int pad = (lastp - k * LPP) >> 31;                           // all ones -> NaN
-                const int bits = __float_as_int(v[k]) | pad;
-                // integer NaN test, kept opaque so the count is not sunk below the sort
-                nan_cnt = opaque(nan_cnt - ((0x7f800000 - (bits & 0x7fffffff)) >> 31));
-                v[k] = nan_to_inf(__int_as_float(bits));
+                v[k] = __int_as_float(__float_as_int(v[k]) | pad);
+            });
+            // clean waves skip the NaN count (see gather_sorted in fast_common.hpp)
+            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+            static_chunks<0, NS / 4, 8>([&](auto K) NL_INL {
+                constexpr int k = 4 * decltype(K)::value;
+                t0 += v[k]; t1 += v[k + 1]; t2 += v[k + 2]; t3 += v[k + 3];
+            });
+            const float total = (t0 + t1) + (t2 + t3);
+            if (__any(!(__builtin_fabsf(total) < __builtin_inff()))) {
+                static_chunks<0, NS, 8>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    nan_cnt = opaque(nan_cnt - ((0x7f800000 - (__float_as_int(v[k]) & 0x7fffffff)) >> 31));
+                });
+            }
+            static_chunks<0, NS, 16>([&](auto K) NL_INL {
+                constexpr int k = decltype(K)::value;
+                v[k] = nan_to_inf(v[k]);
             });
         }
         sort_network<NS>(v);

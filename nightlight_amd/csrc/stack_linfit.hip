@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void stack_linfit_fast_kernel(StackArgs p, Fas
     const int lane = threadIdx.x & 63;
     const unsigned boff = (unsigned)(on ? pix : 0) * 4u;
     float v[NS];
-    const int n = gather_sorted<NS>(p.frames, p.stride, p.n_frames, boff, v);
+    const int n = gather_sorted<NS, 32>(p.frames, p.stride, p.n_frames, boff, v);
 
     // The sorted column never changes; a sample's liveness is one bit of
     // live[].  Initially the n valid samples (positions 0..n-1) are alive.

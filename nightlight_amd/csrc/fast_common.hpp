@@ -194,4 +194,75 @@ __device__ __forceinline__ int gather_sorted(const float *frames, int64_t stride
     return NS - nan_cnt;
 }
 
+// ---- winsorization loop of StackWinsorSigma (stack.go:646-672) on intervals ------
+// The reference repeats { clamp a copy to median -/+ 1.5*std; std = 1.134 *
+// stddev(copy) } until no sample moved or std changed by <= 0.05 %.  Its std is
+// an order-dependent fp32 sum, so the register-resident kernels carry an
+// interval [w_lo, w_hi] that contains it.  The clamp bounds become intervals
+// too; the variance of the clamped copy is monotone in the clamp (narrowing a
+// clamp never increases a pairwise distance), so evaluating it at the tightest
+// clamp (Lp, Hm) and at the loosest (Lm, Hp) brackets it.  Where an exit test is
+// undecidable the reference EITHER left the loop with a value in the current
+// interval OR went on: we go on and keep the hull of every value it may have
+// left with; the clip step must then be unambiguous over that hull.
+struct WinsorInterval {
+    float w_lo, w_hi;              // the reference's current std lies in here
+    float Lm, Lp, Hm, Hp;          // effective clamp: low bound in [Lm, Lp], high bound in [Hm, Hp]
+    float hull_lo, hull_hi;        // values the reference may have left the loop with
+    int guard;
+    bool ch_sure, ch_none;         // "changed > 0" certain / "changed == 0" certain, this round
+
+    __device__ __forceinline__ void start(float s_min, float s_max)
+    {
+        w_lo = s_min; w_hi = s_max;
+        Lm = Lp = -__builtin_inff();           // running max of the low bounds
+        Hm = Hp = __builtin_inff();            // running min of the high bounds
+        hull_lo = __builtin_inff(); hull_hi = -__builtin_inff();
+        guard = 0;
+    }
+    // bounds of this round (stack.go:650-651) and the changed == 0 test (:652-662):
+    // xmin / xmax = smallest / largest surviving sample
+    __device__ __forceinline__ void next_clamp(float median, float xmin, float xmax)
+    {
+        const float tA = __fmul_rn(1.5f, w_lo), tB = __fmul_rn(1.5f, w_hi);
+        const float lo_m = __fsub_rn(median, tB), lo_p = __fsub_rn(median, tA);   // low bound in [lo_m, lo_p]
+        const float hi_m = __fadd_rn(median, tA), hi_p = __fadd_rn(median, tB);   // high bound in [hi_m, hi_p]
+        const float wmin_m = fmaxf(xmin, Lm), wmin_p = fmaxf(xmin, Lp);           // smallest value of the copy
+        const float wmax_m = fminf(xmax, Hm), wmax_p = fminf(xmax, Hp);           // largest
+        ch_sure = (wmin_p < lo_m) || (wmax_m > hi_p);
+        ch_none = (wmin_m >= lo_p) && (wmax_p <= hi_m);
+        Lm = fmaxf(Lm, lo_m); Lp = fmaxf(Lp, lo_p);
+        Hm = fminf(Hm, hi_m); Hp = fminf(Hp, hi_p);
+    }
+    // var_t +- err_t: variance of the copy at the tightest clamp, var_l +- err_l at the
+    // loosest; eps_r, e_m: rounding of the reference's own MeanStdDev.
+    // Clears `inner` when the loop is certainly over, sets `bail` if the pixel has to be
+    // replayed exactly.
+    __device__ __forceinline__ void finish_round(float var_t, float err_t, float var_l, float err_l,
+                                                 float eps_r, float e_m, bool shape_ok, bool &inner, bool &bail)
+    {
+        const float w_up = var_l + err_l;
+        const float w_dn = fmaxf(var_t - err_t, 0.0f);
+        // hardware sqrt (1 ulp, flushes denormals): the 4u margins and the absolute term cover it
+        const float r_hi = __builtin_amdgcn_sqrtf(w_up + w_up * eps_r + e_m * e_m) * (1.0f + 4.0f * kU) + 4.0e-19f;
+        const float r_lo = __builtin_amdgcn_sqrtf(fmaxf(w_dn - w_dn * eps_r, 0.0f)) * (1.0f - 4.0f * kU);
+        const float n_lo = __fmul_rn(1.134f, r_lo), n_hi = __fmul_rn(1.134f, r_hi);
+        // factor = |new - old| / old <= 0.0005 (stack.go:668-669) without the division:
+        // fl(x/y) <= t follows from x <= y*t*(1-4u), fl(x/y) > t from x > y*t*(1+4u)
+        const float dmin = __fsub_rn(n_lo, w_hi), dmax = __fsub_rn(n_hi, w_lo);
+        const float amin = (dmin <= 0.0f && dmax >= 0.0f) ? 0.0f : fminf(fabsf(dmin), fabsf(dmax));
+        const float amx = fmaxf(fabsf(dmin), fabsf(dmax));
+        const bool stop_sure = w_lo > 0.0f && amx <= w_lo * (0.0005f * (1.0f - 4.0f * kU));
+        const bool go_sure = amin > w_hi * (0.0005f * (1.0f + 4.0f * kU));
+        if (inner) {
+            w_lo = n_lo; w_hi = n_hi;
+            const bool may_stop = !ch_sure || !go_sure;
+            const bool must_stop = ch_none || stop_sure;          // implies may_stop
+            if (may_stop) { hull_lo = fminf(hull_lo, w_lo); hull_hi = fmaxf(hull_hi, w_hi); }
+            if (!shape_ok || !(w_hi < 3.0e38f) || ++guard > 100) { bail = true; inner = false; }
+            else if (must_stop) inner = false;
+        }
+    }
+};
+
 }  // namespace nl

@@ -392,7 +392,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
             NL_HIP(nl::launch_stack_sigma_fast(a, f, &fast_grid, h->stream, &h->last_kernel, h->ev_dom1,
                                                mode == NL_ST_WINSOR_SIGMA));
         else   // 129..512 frames: 2 or 4 lanes per pixel
-            NL_HIP(nl::launch_stack_sigma_ml(a, f, h->stream, &h->last_kernel, h->ev_dom1));
+            NL_HIP(nl::launch_stack_sigma_ml(a, f, h->stream, &h->last_kernel, h->ev_dom1,
+                                             mode == NL_ST_WINSOR_SIGMA));
         // exact replay of the undecidable pixels: one wave per pixel where available
         nl::StackArgs e = a;
         e.list = h->d_fb_list;

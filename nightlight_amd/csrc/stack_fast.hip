@@ -222,31 +222,16 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                 // The reference repeats { clamp a copy to median -/+ 1.5*std; std =
                 // 1.134*stddev(copy) } until nothing changed or std moved by <= 0.05 %.
                 // Its std is again an order-dependent fp32 sum, so we carry an interval
-                // [w_lo, w_hi] for it through the loop: the clamp bounds become
-                // intervals and the copy's variance is evaluated at the tightest and at
-                // the loosest clamp of the interval (it is monotone in the clamp).
+                // [w_lo, w_hi] for it through the loop (WinsorInterval, fast_common.hpp).
                 constexpr int PZ = ZONAL ? ZH : 0;
                 const float xmin = pick<0, ZONAL ? ZL : NS>(v, a);
                 const float xmax = pick<PZ, NS>(v, b - 1);
-                float w_lo = s_min, w_hi = s_max;
-                float Lm = -__builtin_inff(), Lp = -__builtin_inff();     // running max of the low bounds
-                float Hm = __builtin_inff(), Hp = __builtin_inff();       // running min of the high bounds
-                float f_lo_hull = __builtin_inff(), f_hi_hull = -__builtin_inff();
+                WinsorInterval wi;
+                wi.start(s_min, s_max);
                 const float inv_cnt = 1.0f / fcnt;
                 bool inner = active && !bail;
-                int guard = 0;
                 while (__any(inner)) {
-                    const float tA = __fmul_rn(1.5f, w_lo), tB = __fmul_rn(1.5f, w_hi);
-                    const float lo_m = __fsub_rn(median, tB), lo_p = __fsub_rn(median, tA);   // lo_j in [lo_m, lo_p]
-                    const float hi_m = __fadd_rn(median, tA), hi_p = __fadd_rn(median, tB);   // hi_j in [hi_m, hi_p]
-                    // changed == 0 ?  (smallest / largest value of the copy against the new bounds)
-                    const float wmin_m = fmaxf(xmin, Lm), wmin_p = fmaxf(xmin, Lp);
-                    const float wmax_m = fminf(xmax, Hm), wmax_p = fminf(xmax, Hp);
-                    const bool ch_sure = (wmin_p < lo_m) || (wmax_m > hi_p);
-                    const bool ch_none = (wmin_m >= lo_p) && (wmax_p <= hi_m);
-                    // new effective clamp
-                    Lm = fmaxf(Lm, lo_m); Lp = fmaxf(Lp, lo_p);
-                    Hm = fminf(Hm, hi_m); Hp = fminf(Hp, hi_p);
+                    wi.next_clamp(median, xmin, xmax);
                     // variance of clamp(x, Lt, Ht) over the survivors (shifted moments) and its error bound
                     auto clamped_variance = [&](const float Lt, const float Ht, float &wvar, float &werr) NL_INL {
                     float d0 = 0, d1 = 0, d2 = 0, d3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
@@ -303,44 +288,15 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                     wvar = fmaxf(wa - wb, 0.0f);
                     werr = ((float)(NS / 4 + 34)) * kU * (wa + wb);
                     };
-                    // Clamping to a narrower range never increases a pairwise distance, so
-                    // the variance is monotone in the clamp: the tightest clamp of the
-                    // interval bounds it from below, the loosest from above.
                     float var_t, err_t, var_l, err_l;
-                    clamped_variance(Lp, Hm, var_t, err_t);
-                    clamped_variance(Lm, Hp, var_l, err_l);
-                    const float w_up = var_l + err_l;
-                    const float w_dn = fmaxf(var_t - err_t, 0.0f);
-                    // hardware sqrt (1 ulp, flushes denormals): the 4u margins and the absolute
-                    // term cover it
-                    const float r_hi = __builtin_amdgcn_sqrtf(w_up + w_up * eps_r + e_m * e_m) * (1.0f + 4.0f * kU) + 4.0e-19f;
-                    const float r_lo = __builtin_amdgcn_sqrtf(fmaxf(w_dn - w_dn * eps_r, 0.0f)) * (1.0f - 4.0f * kU);
-                    const float n_lo_s = __fmul_rn(1.134f, r_lo), n_hi_s = __fmul_rn(1.134f, r_hi);
-                    // factor = |new - old| / old <= 0.0005  (stack.go:668-669) over both intervals,
-                    // without the division: fl(x/y) <= t follows from x <= y*t*(1-4u), and
-                    // fl(x/y) > t from x > y*t*(1+4u)
-                    const float dmin = __fsub_rn(n_lo_s, w_hi), dmax = __fsub_rn(n_hi_s, w_lo);
-                    const float amin = (dmin <= 0.0f && dmax >= 0.0f) ? 0.0f : fminf(fabsf(dmin), fabsf(dmax));
-                    const float amx = fmaxf(fabsf(dmin), fabsf(dmax));
-                    const bool stop_sure = w_lo > 0.0f && amx <= w_lo * (0.0005f * (1.0f - 4.0f * kU));
-                    const bool go_sure = amin > w_hi * (0.0005f * (1.0f + 4.0f * kU));
-                    if (inner) {
-                        w_lo = n_lo_s; w_hi = n_hi_s;
-                        // Where an exit test is undecidable the reference EITHER left the
-                        // loop with a value in [w_lo, w_hi] OR went on; we go on and keep the
-                        // hull of every value it may have left with.  The clip step below
-                        // then has to be unambiguous over that hull (0.05 % wide at worst).
-                        const bool may_stop = !ch_sure || !go_sure;
-                        const bool must_stop = ch_none || stop_sure;         // implies may_stop
-                        if (may_stop) { f_lo_hull = fminf(f_lo_hull, w_lo); f_hi_hull = fmaxf(f_hi_hull, w_hi); }
-                        // zonal: the inner half must be strictly inside every clamp of the interval
-                        const bool shape_ok = !ZONAL || (v[WL] >= Lp && v[WH - 1] <= Hm);
-                        if (!shape_ok || !(w_hi < 3.0e38f) || ++guard > 100) { bail = true; inner = false; }
-                        else if (must_stop) inner = false;
-                    }
+                    clamped_variance(wi.Lp, wi.Hm, var_t, err_t);
+                    clamped_variance(wi.Lm, wi.Hp, var_l, err_l);
+                    // zonal: the inner half must be strictly inside every clamp of the interval
+                    const bool shape_ok = !ZONAL || (v[WL] >= wi.Lp && v[WH - 1] <= wi.Hm);
+                    wi.finish_round(var_t, err_t, var_l, err_l, eps_r, e_m, shape_ok, inner, bail);
                 }
-                s_min = f_lo_hull;
-                s_max = f_hi_hull;
+                s_min = wi.hull_lo;
+                s_max = wi.hull_hi;
             }
 
             // ---- the reference's bound expressions at both ends of the interval ----

@@ -131,7 +131,7 @@ __device__ __forceinline__ float pick_rank(const float (&v)[NS], int g, int role
 }
 
 // ZONAL / generic exactly as in stack_fast.hip; LPP lanes per pixel.
-template <int LPP, bool ZONAL>
+template <int LPP, bool ZONAL, bool WINSOR>
 __global__ __launch_bounds__(256) void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
 {
     constexpr int NS = kMlNS, NT = NS * LPP;
@@ -337,8 +337,8 @@ __global__ __launch_bounds__(256) void stack_sigma_ml_kernel(StackArgs p, FastAr
             const float v_dn = fmaxf(var - err_o, 0.0f);
             const float v_hi = v_up + v_up * eps_r + e_m * e_m;
             const float v_lo = fmaxf(v_dn - v_dn * eps_r, 0.0f);
-            const float s_max = __fsqrt_rn(v_hi) * (1.0f + 4.0f * kU);
-            const float s_min = __fsqrt_rn(v_lo) * (1.0f - 4.0f * kU);
+            float s_max = __fsqrt_rn(v_hi) * (1.0f + 4.0f * kU);
+            float s_min = __fsqrt_rn(v_lo) * (1.0f - 4.0f * kU);
             bool bail = !(v_hi < 3.0e38f);
 
             // ---- exact median (qsort.go:68-82) ----
@@ -346,6 +346,78 @@ __global__ __launch_bounds__(256) void stack_sigma_ml_kernel(StackArgs p, FastAr
             const float upper = pick_rank<LPP, NS, TOPW, BOTW>(v, kk, role, MIDR);
             const float lower = pick_rank<LPP, NS, TOPW, BOTW>(v, kk - 1, role, MIDR);
             const float median = (cnt & 1) ? upper : 0.5f * (lower + upper);
+
+            if constexpr (WINSOR) {
+                // ---- winsorized stddev (stack.go:646-672) as an interval, see
+                // WinsorInterval in fast_common.hpp.  Every lane clamps its own NS
+                // ranks; the four partial sums meet in quad_sum. ----
+                const float xmin = ZONAL ? pick_rank<LPP, NS, 1, ZL>(v, a, role, -1)
+                                         : pick_rank<LPP, NS, NS, NS>(v, a, role, 0);
+                const float xmax = ZONAL ? pick_rank<LPP, NS, ZHS, 1>(v, b - 1, role, LAST)
+                                         : pick_rank<LPP, NS, NS, NS>(v, b - 1, role, 0);
+                WinsorInterval wi;
+                wi.start(s_min, s_max);
+                const float inv_cnt = 1.0f / fcnt;
+                bool inner = active && !bail;
+                // ranks below a / from b on are excluded: only lane 0 / the last lane see them
+                const int a_loc = role == 0 ? a : 0;
+                const int b_loc = role == LAST ? b - LAST * NS : NS;
+                while (__any(inner)) {
+                    wi.next_clamp(median, xmin, xmax);
+                    auto clamped_variance = [&](const float Lt, const float Ht, float &wvar, float &werr) NL_INL {
+                        float d0 = 0, d1 = 0, d2 = 0, d3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+                        if constexpr (ZONAL) {
+                            static_range<0, ZL>([&](auto K) NL_INL {
+                                constexpr int k = decltype(K)::value;
+                                const float e = (k >= a_loc) ? __builtin_amdgcn_fmed3f(v[k], Lt, Ht) - c : 0.0f;
+                                d0 += e; q0 = __builtin_fmaf(e, e, q0);
+                            });
+                            static_chunks<0, (NS - ZHS - ZL) / 4, 4>([&](auto K) NL_INL {
+                                constexpr int k = ZL + 4 * decltype(K)::value;
+                                const float e0 = __builtin_amdgcn_fmed3f(v[k], Lt, Ht) - c;
+                                const float e1 = __builtin_amdgcn_fmed3f(v[k + 1], Lt, Ht) - c;
+                                const float e2 = __builtin_amdgcn_fmed3f(v[k + 2], Lt, Ht) - c;
+                                const float e3 = __builtin_amdgcn_fmed3f(v[k + 3], Lt, Ht) - c;
+                                d0 += e0; d1 += e1; d2 += e2; d3 += e3;
+                                q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
+                                q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
+                            });
+                            static_range<NS - ZHS, NS>([&](auto K) NL_INL {
+                                constexpr int k = decltype(K)::value;
+                                const float e = (k < b_loc) ? __builtin_amdgcn_fmed3f(v[k], Lt, Ht) - c : 0.0f;
+                                d1 += e; q1 = __builtin_fmaf(e, e, q1);
+                            });
+                        } else {
+                            const int a4 = opaque(a - role * NS);
+                            static_chunks<0, NS / 4, 2>([&](auto K) NL_INL {
+                                constexpr int k = 4 * decltype(K)::value;
+                                const bool i0 = (unsigned)(k + 0 - a4) < (unsigned)cnt;
+                                const bool i1 = (unsigned)(k + 1 - a4) < (unsigned)cnt;
+                                const bool i2 = (unsigned)(k + 2 - a4) < (unsigned)cnt;
+                                const bool i3 = (unsigned)(k + 3 - a4) < (unsigned)cnt;
+                                const float e0 = i0 ? __builtin_amdgcn_fmed3f(v[k + 0], Lt, Ht) - c : 0.0f;
+                                const float e1 = i1 ? __builtin_amdgcn_fmed3f(v[k + 1], Lt, Ht) - c : 0.0f;
+                                const float e2 = i2 ? __builtin_amdgcn_fmed3f(v[k + 2], Lt, Ht) - c : 0.0f;
+                                const float e3 = i3 ? __builtin_amdgcn_fmed3f(v[k + 3], Lt, Ht) - c : 0.0f;
+                                d0 += e0; d1 += e1; d2 += e2; d3 += e3;
+                                q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
+                                q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
+                            });
+                        }
+                        const float wd = quad_sum<LPP>((d0 + d1) + (d2 + d3)) * inv_cnt;
+                        const float wa = quad_sum<LPP>((q0 + q1) + (q2 + q3)) * inv_cnt;
+                        const float wb = wd * wd;
+                        wvar = fmaxf(wa - wb, 0.0f);
+                        werr = ((float)(NS / 4 + 40)) * kU * (wa + wb);
+                    };
+                    float var_t, err_t, var_l, err_l;
+                    clamped_variance(wi.Lp, wi.Hm, var_t, err_t);
+                    clamped_variance(wi.Lm, wi.Hp, var_l, err_l);
+                    wi.finish_round(var_t, err_t, var_l, err_l, eps_r, e_m, true, inner, bail);
+                }
+                s_min = wi.hull_lo;
+                s_max = wi.hull_hi;
+            }
 
             // ---- the reference's bound expressions (stack.go:408-409) at both ends ----
             const float tl0 = __fmul_rn(p.sig_lo, s_min), tl1 = __fmul_rn(p.sig_lo, s_max);
@@ -455,10 +527,11 @@ __global__ __launch_bounds__(256) void stack_sigma_ml_kernel(StackArgs p, FastAr
 
 int fast_ml_supported(int mode, bool weighted, int n_frames)
 {
-    return (mode == NL_ST_SIGMA && !weighted && n_frames > 128 && n_frames <= 512) ? 1 : 0;
+    return ((mode == NL_ST_SIGMA || mode == NL_ST_WINSOR_SIGMA) && !weighted && n_frames > 128 && n_frames <= 512)
+               ? 1 : 0;
 }
 
-template <int LPP>
+template <int LPP, bool WINSOR>
 static void launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
                       hipEvent_t dominant_done)
 {
@@ -468,24 +541,27 @@ static void launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t 
     f.in_list = nullptr;
     f.in_count = nullptr;
     f.in_capacity = 0;
-    hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, true>), dim3(tile_blocks), dim3(256), 0, stream, args, f);
+    hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, true, WINSOR>), dim3(tile_blocks), dim3(256), 0, stream, args, f);
     if (dominant_done) (void)hipEventRecord(dominant_done, stream);
     f.in_list = fargs.gen_list;
     f.in_count = fargs.gen_count;
     f.in_capacity = fargs.gen_capacity;
     const unsigned gblocks = tile_blocks < kGenericGrid ? tile_blocks : kGenericGrid;
-    hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, false>), dim3(gblocks), dim3(256), 0, stream, args, f);
+    hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, false, WINSOR>), dim3(gblocks), dim3(256), 0, stream, args, f);
 }
 
+// kernel names as rocprofv3 prints them (template arguments: LPP, ZONAL, WINSOR)
 hipError_t launch_stack_sigma_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
-                                 const char **name, hipEvent_t dominant_done)
+                                 const char **name, hipEvent_t dominant_done, bool winsor)
 {
     if (args.n_frames <= 256) {
-        *name = "stack_sigma_ml_kernel<2, true>";
-        launch_ml<2>(args, fargs, stream, dominant_done);
+        *name = winsor ? "stack_sigma_ml_kernel<2, true, true>" : "stack_sigma_ml_kernel<2, true, false>";
+        if (winsor) launch_ml<2, true>(args, fargs, stream, dominant_done);
+        else        launch_ml<2, false>(args, fargs, stream, dominant_done);
     } else {
-        *name = "stack_sigma_ml_kernel<4, true>";
-        launch_ml<4>(args, fargs, stream, dominant_done);
+        *name = winsor ? "stack_sigma_ml_kernel<4, true, true>" : "stack_sigma_ml_kernel<4, true, false>";
+        if (winsor) launch_ml<4, true>(args, fargs, stream, dominant_done);
+        else        launch_ml<4, false>(args, fargs, stream, dominant_done);
     }
     return hipGetLastError();
 }

@@ -63,7 +63,7 @@ hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs,
 // ---- stack_fast_ml.hip (129..512 frames, 2 or 4 lanes per pixel) ----
 int fast_ml_supported(int mode, bool weighted, int n_frames);
 hipError_t launch_stack_sigma_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
-                                 const char **name, hipEvent_t dominant_done);
+                                 const char **name, hipEvent_t dominant_done, bool winsor);
 
 // ---- stack_exact_coop.hip (bit-exact sigma replay, one wave per pixel) ----
 int coop_supported(int mode, bool weighted, int n_frames);

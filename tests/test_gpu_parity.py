@@ -108,6 +108,21 @@ def test_fast_median_is_bit_exact(nl, oracle, n):
     assert same_values(got, want), "fast median n=%d: %s" % (n, describe_mismatch(got, want))
 
 
+@pytest.mark.parametrize("n", [129, 200, 256, 257, 384, 512])
+@pytest.mark.parametrize("clean", [False, True])
+def test_multi_lane_winsor_129_to_512_frames(nl, oracle, n, clean):
+    # the winsorized variant of the multi-lane kernel (configuration C3: 512 frames)
+    width, height = 67, 9
+    if clean:
+        frames = make_frames(n, width, height, seed=800 + n, nan_frac=0.0, nan_border=False,
+                             all_nan_patch=False)
+    else:
+        frames = make_frames(n, width, height, seed=800 + n, nan_frac=0.01)
+    got, gc, want, wc = run_both(nl, oracle, 3, frames, width, height, None, 3.0, 2.5, exact=False)
+    assert gc == wc, "multi-lane winsor n=%d clip counters %r vs oracle %r" % (n, gc, wc)
+    assert close_values(got, want), "multi-lane winsor n=%d: %s" % (n, describe_mismatch(got, want))
+
+
 @pytest.mark.parametrize("n", [129, 200, 256, 257, 300, 384, 500, 512])
 @pytest.mark.parametrize("clean", [False, True])
 def test_multi_lane_sigma_129_to_512_frames(nl, oracle, n, clean):

@@ -375,7 +375,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         h->last_has_counters = true;
         h->last_used_fast = true;
     } else if (!h->force_exact && h->d_fb_list &&
-               (nl::fast_supported(mode, weighted, a.n_frames) || nl::fast_ml_supported(mode, weighted, a.n_frames))) {
+               (nl::fast_supported(mode, weighted, a.n_frames) || nl::fast_ml_supported(mode, weighted, a.n_frames, a.npix))) {
         // register-resident fast kernel; pixels it cannot decide go to the exact kernel
         nl::FastArgs f;
         f.fb_list = h->d_fb_list;

@@ -79,6 +79,31 @@ __device__ __forceinline__ void half_clean(float (&v)[NS])
     }
 }
 
+// The last merge of the zonal kernels: only the KEEP lowest and KEEP highest
+// positions of the lane must end up sorted (clip zones, median window); all
+// other positions are only ever summed, so they merely have to hold the right
+// SET.  A half-cleaner block that cannot reach either end is skipped:
+// 224 instead of 448 compare-exchanges for NS = 128, KEEP = 16.
+template <int NS, int D, int KEEP>
+__device__ __forceinline__ void half_clean_ends(float (&v)[NS])
+{
+    if constexpr (D >= 1) {
+        static_chunks<0, NS / 2, 32>([&](auto T) NL_INL {
+            constexpr int t = decltype(T)::value;
+            constexpr int i = ((t & ~(D - 1)) << 1) | (t & (D - 1));
+            constexpr int l = i | D;
+            constexpr int blk = i & ~(2 * D - 1);                 // this comparator's block [blk, blk + 2D)
+            if constexpr (blk < KEEP || blk + 2 * D > NS - KEEP) {
+                const float lo = fminf(v[i], v[l]);
+                const float hi = fmaxf(v[i], v[l]);
+                v[i] = lo;
+                v[l] = hi;
+            }
+        });
+        half_clean_ends<NS, (D >> 1), KEEP>(v);
+    }
+}
+
 // cross-lane stage against the partner selected by CTRL; MIRROR: element i
 // meets the partner's element NS-1-i (first stage of merging two ascending
 // runs), else element i meets element i (half-cleaner at lane distance)
@@ -131,8 +156,10 @@ __device__ __forceinline__ float pick_rank(const float (&v)[NS], int g, int role
 }
 
 // ZONAL / generic exactly as in stack_fast.hip; LPP lanes per pixel.
+// (zonal sigma: the allocator lands one register above the 168 that let 3 waves share a SIMD)
 template <int LPP, bool ZONAL, bool WINSOR>
-__global__ __launch_bounds__(256) void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZONAL && !WINSOR ? 3 : 1, 8)))
+void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
 {
     constexpr int NS = kMlNS, NT = NS * LPP;
     constexpr int ZL = kZone;                        // low zone : ranks [0, ZL)           (role 0)
@@ -156,42 +183,36 @@ __global__ __launch_bounds__(256) void stack_sigma_ml_kernel(StackArgs p, FastAr
         int64_t pix = item;
         if (listed) pix = on ? (int64_t)q.in_list[item] : 0;
 
-        // ---- gather: lane role r takes frames [r*NS, r*NS+NS); positions past the
-        // last frame re-read it and are turned into missing samples ----
+        // ---- gather ----
         float v[NS];
         int nan_cnt = 0;
         {
             // Frames are dealt round-robin: lane role r takes frames r, r+LPP, ...
-            // (any split works, the column is sorted afterwards).  Buffer loads:
-            // scalar descriptor per register index k (frames k*LPP .. k*LPP+LPP-1),
-            // per-lane byte offset = pixel + role * frame; indices are clamped to
-            // the last frame and the surplus positions become missing samples.
-            const int frame_bytes = (int)(p.stride * (int64_t)sizeof(float));
-            const int last = N - 1;
-            const int boff = (int)((unsigned)(on ? pix : 0) * 4u);
-            // A per-lane pointer walks the lane's frames (role, role+LPP, ...): it
-            // advances by LPP frames while the next frame exists and then stays on
-            // the lane's last frame (valid address; the surplus positions are
-            // marked missing below).  The step is masked arithmetically -- no
-            // branches, no lane masks -- and the chain keeps register pressure low.
-            const int64_t step = (int64_t)LPP * frame_bytes;
-            const int first = min(role, last);
-            const char *fk = reinterpret_cast<const char *>(p.frames) + (int64_t)first * frame_bytes + boff;
-            // lastr - k*LPP < 0  <=>  frame k*LPP+role does not exist.  lastr is
-            // re-materialised every 8 steps so these per-lane tests are computed
-            // where they are used instead of 128 of them being kept in registers.
-            int lastr = last - role;
-            static_chunks<0, NS, 16>([&](auto K) NL_INL {
+            // (any split works, the column is sorted afterwards).  Buffer loads: one
+            // scalar descriptor per register index k covering frames k*LPP .. k*LPP+LPP-1,
+            // per-lane byte offset = pixel + role * frame.  The descriptor's size is
+            // cut at the last existing frame, so a lane whose frame k*LPP+role does
+            // not exist reads out of range -- the hardware returns 0 without touching
+            // memory -- and the position is marked missing below.  No per-lane
+            // addresses, no branches; descriptors are scalar work.
+            int frame_bytes = (int)(p.stride * (int64_t)sizeof(float));           // LPP*frame_bytes < 2^31 (dispatch)
+            // opaque per trip: otherwise the 128 descriptors are hoisted out of the
+            // item loop as loop invariants and spilled
+            asm volatile("" : "+s"(frame_bytes));
+            const int voff = (int)((unsigned)(on ? pix : 0) * 4u) + role * frame_bytes;
+            static_chunks<0, NS, 4>([&](auto K) NL_INL {
                 constexpr int k = decltype(K)::value;
-                if constexpr ((k & 7) == 0) lastr = opaque(lastr);
-                v[k] = *reinterpret_cast<const float *>(fk);
-                const int64_t stop = (int64_t)((lastr - (k + 1) * LPP) >> 31);      // next frame missing: -1
-                fk += step & ~stop;
+                const int avail = min(max(N - k * LPP, 0), LPP);                // frames this descriptor covers
+                const char *gb = reinterpret_cast<const char *>(p.frames) + (int64_t)(k * LPP) * frame_bytes;
+                const __amdgpu_buffer_rsrc_t rs =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gb), 0, avail * frame_bytes, 0x00020000);
+                v[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
             });
-            // surplus positions (frame k*LPP+role does not exist) become NaN = missing;
-            // only the last positions can be surplus: N > (LPP-1)*NS by the choice of LPP
-            int lastp = opaque(last) - role;
-            static_chunks<0, NS, 8>([&](auto K) NL_INL {
+            // frame k*LPP+role >= N: missing (NaN).  Only k >= KPAD0 can be affected:
+            // this kernel is used for N > NT/2.
+            constexpr int KPAD0 = NS / 2;
+            int lastp = opaque(N - 1) - role;
+            static_chunks<KPAD0, NS, 8>([&](auto K) NL_INL {
                 constexpr int k = decltype(K)::value;
                 if constexpr ((k & 7) == 0) lastp = opaque(lastp);
                 const int pad = (lastp - k * LPP) >> 31;                           // all ones -> NaN
@@ -217,12 +238,17 @@ __global__ __launch_bounds__(256) void stack_sigma_ml_kernel(StackArgs p, FastAr
         }
         sort_network<NS>(v);
         // ---- merge the LPP sorted runs: lane r ends up with ranks [r*NS, r*NS+NS) ----
+        // (zonal: the final half-cleaners only order the ends of each lane, see half_clean_ends)
+        constexpr int KEEP = 16;
+        static_assert(kZone + kPadMax <= KEEP, "zones must lie inside the sorted ends");
         cross_stage<NS, kSwap1, true>(v, (role & 1) == 0);
-        half_clean<NS, NS / 2>(v);
+        if constexpr (ZONAL && LPP == 2) half_clean_ends<NS, NS / 2, KEEP>(v);
+        else                             half_clean<NS, NS / 2>(v);
         if constexpr (LPP == 4) {
             cross_stage<NS, kMirror, true>(v, role < 2);
             cross_stage<NS, kSwap1, false>(v, (role & 1) == 0);
-            half_clean<NS, NS / 2>(v);
+            if constexpr (ZONAL) half_clean_ends<NS, NS / 2, KEEP>(v);
+            else                 half_clean<NS, NS / 2>(v);
         }
         const int n = quad_sum<LPP>(NS - nan_cnt);
 
@@ -525,10 +551,11 @@ __global__ __launch_bounds__(256) void stack_sigma_ml_kernel(StackArgs p, FastAr
     }
 }
 
-int fast_ml_supported(int mode, bool weighted, int n_frames)
+int fast_ml_supported(int mode, bool weighted, int n_frames, int64_t npix)
 {
-    return ((mode == NL_ST_SIGMA || mode == NL_ST_WINSOR_SIGMA) && !weighted && n_frames > 128 && n_frames <= 512)
-               ? 1 : 0;
+    // 4 frames of the tile must be addressable with a 31-bit buffer offset
+    return ((mode == NL_ST_SIGMA || mode == NL_ST_WINSOR_SIGMA) && !weighted && n_frames > 128 && n_frames <= 512 &&
+            npix < ((int64_t)1 << 27)) ? 1 : 0;
 }
 
 template <int LPP, bool WINSOR>

@@ -172,6 +172,44 @@ int nl_stack_frame_noise(nl_stack_t *h, int idx, float *noise);
  * (stack.go:241-253).  noise_out: n_frames floats or NULL. */
 int nl_stack_weights_from_noise(nl_stack_t *h, float *noise_out);
 
+/* ---- formats and steps either side of the stack (F3, F4) ----
+ * A frame goes from its on-disk bytes to its slot of the stack buffer without
+ * a CPU pass.  All of these are bit-exact restatements (elementwise fp32, the
+ * reference's operation order).
+ *
+ * nl_stack_upload_frame_fits: internal/fits/read.go:172-445 (readUint8Data ..
+ * readFloat64Data).  raw_host = the big-endian FITS payload bytes of exactly the
+ * handle's tile (rows*width values of BITPIX 8/16/32/64/-32/-64; row-major, so
+ * a row tile is a contiguous byte range of the file).  v = float32(val)*bscale
+ * + bzero.  stats_out (3 floats or NULL) = min, max, mean of the decoded tile
+ * (mean through an fp64 sum, read.go:210).  multiplier/offset: MatchHistogram
+ * (internal/fits/pixelops.go:601-605) fused behind the decode; pass 1, 0 for
+ * none (then nothing is applied). */
+int nl_stack_upload_frame_fits(nl_stack_t *h, int idx, const void *raw_host, int bitpix,
+                               float bscale, float bzero, float multiplier, float offset,
+                               float *stats_out);
+/* nl_stack_upload_frame_projected: Image.Project (internal/fits/project.go:26-76)
+ * straight into the frame slot.  src_host = the WHOLE unaligned frame
+ * (src_w x src_h fp32); trans = the forward Transform2D {A,B,C,D,E,F}
+ * (internal/star/coord.go:52-59), inverted as coord.go:159-199 (singular ->
+ * NL_ERR_INVALID_ARG, the reference returns an error too); bilinear taps with
+ * the reference's fp32 expressions; destination pixels whose taps leave the
+ * source get out_of_bounds (NaN in the pipeline = "no data" for the stack).
+ * Only the handle's rows are produced.  multiplier/offset as above. */
+int nl_stack_upload_frame_projected(nl_stack_t *h, int idx, const float *src_host, int src_w,
+                                    int src_h, const float trans[6], float out_of_bounds,
+                                    float multiplier, float offset);
+/* MatchHistogram on a resident frame: x = x*multiplier + offset (pixelops.go:601-605). */
+int nl_stack_frame_affine(nl_stack_t *h, int idx, float multiplier, float offset);
+/* The result tile of the last pass as FITS payload bytes: big-endian fp32, NaN
+ * replaced by 0 (internal/fits/write.go:88, 182-200).  raw_host: rows*width*4 bytes. */
+int nl_stack_download_result_fits(nl_stack_t *h, void *raw_host);
+/* Stand-alone forms (host in, host out) of the decode and the projection. */
+int nl_fits_decode(const void *raw_host, int bitpix, int64_t n, float bscale, float bzero,
+                   float *out_host, float *stats_out, int device);
+int nl_project_bilinear(const float *src_host, int src_w, int src_h, float *dst_host, int dst_w,
+                        int dst_h, const float trans[6], float out_of_bounds, int device);
+
 /* ---- 3x3 spatial median filter (internal/median/median3x3.go:26-110) ----
  * host in/out, width*height floats each; border rows/columns copied. */
 int nl_median_filter_3x3(const float *in_host, float *out_host, int width, int height, int device);

@@ -76,6 +76,8 @@ struct nl_stack {
     bool last_used_fast = false;
     unsigned long long *d_counters = nullptr;  // [2]
     double *d_stat_partial = nullptr;          // [kStatBlocks*3]
+    void *d_ingest = nullptr;                  // raw FITS bytes / unaligned source frame, grown on demand
+    size_t ingest_bytes = 0;
     int max_grid = 0;
     int last_mode = -1;
     bool last_has_counters = false;
@@ -112,6 +114,7 @@ static int destroy_impl(nl_stack_t *h)
     if (h->d_gen_list) (void)hipFree(h->d_gen_list);
     if (h->d_counters) (void)hipFree(h->d_counters);
     if (h->d_stat_partial) (void)hipFree(h->d_stat_partial);
+    if (h->d_ingest) (void)hipFree(h->d_ingest);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
     if (h->ev_dom0) (void)hipEventDestroy(h->ev_dom0);
@@ -653,6 +656,152 @@ int nl_stack_weights_from_noise(nl_stack_t *h, float *noise_out)
     int rc = nl_weights_from_scalars(NL_WEIGHT_INVERSE_NOISE, noise.data(), h->n_frames, w.data(), nullptr);
     if (rc != NL_OK) return rc;
     return nl_stack_set_weights(h, w.data());
+}
+
+// ---- formats and steps either side of the stack (ingest.hip) ----------------------
+static int ingest_reserve(nl_stack_t *h, size_t bytes)
+{
+    if (bytes <= h->ingest_bytes) return NL_OK;
+    if (h->d_ingest) { (void)hipFree(h->d_ingest); h->d_ingest = nullptr; h->ingest_bytes = 0; }
+    NL_HIP(hipMalloc(&h->d_ingest, bytes));
+    h->ingest_bytes = bytes;
+    return NL_OK;
+}
+
+// min / max / mean from the decode kernel's per-block partials (read.go:210: mean = float32(sum/len))
+static int decode_stats(nl_stack_t *h, int64_t n, float *stats_out)
+{
+    std::vector<double> part(3 * kStatBlocks);
+    NL_HIP(hipMemcpyAsync(part.data(), h->d_stat_partial, sizeof(double) * 3 * kStatBlocks,
+                          hipMemcpyDeviceToHost, h->stream));
+    NL_HIP(hipStreamSynchronize(h->stream));
+    float lo = (float)part[0], hi = (float)part[1];
+    double sum = 0.0;
+    for (int b = 0; b < kStatBlocks; b++) {
+        const float bl = (float)part[3 * b], bh = (float)part[3 * b + 1];
+        if (bl < lo) lo = bl;
+        if (bh > hi) hi = bh;
+        sum += part[3 * b + 2];
+    }
+    stats_out[0] = lo;
+    stats_out[1] = hi;
+    stats_out[2] = (float)(sum / (double)n);
+    return NL_OK;
+}
+
+// internal/star/coord.go:159-199, fp32 as written there
+static int invert_transform(const float t[6], float inv[6])
+{
+    const volatile float bd = t[1] * t[3], ae = t[0] * t[4];
+    const float eps = bd - ae;
+    if (eps < 1e-8f && -eps < 1e-8f) return fail(NL_ERR_INVALID_ARG, "Matrix has no inverse, epsilon=%g", eps);
+    const volatile float den1 = bd - ae, den2 = ae - bd;
+    const volatile float ce = t[2] * t[4], bf = t[1] * t[5], cd = t[2] * t[3], af = t[0] * t[5];
+    const volatile float n1 = ce - bf, n2 = cd - af;
+    inv[0] = -t[4] / den1;
+    inv[1] = t[1] / den1;
+    inv[2] = n1 / den1;
+    inv[3] = -t[3] / den2;
+    inv[4] = t[0] / den2;
+    inv[5] = n2 / den2;
+    return NL_OK;
+}
+
+int nl_stack_upload_frame_fits(nl_stack_t *h, int idx, const void *raw_host, int bitpix, float bscale,
+                               float bzero, float multiplier, float offset, float *stats_out)
+{
+    NL_CHECK_HANDLE(h);
+    if (idx < 0 || idx >= h->n_frames || !raw_host)
+        return fail(NL_ERR_INVALID_ARG, "upload_frame_fits: bad index %d or null payload", idx);
+    const int bpv = nl::fits_bytes_per_value(bitpix);
+    if (bpv == 0) return fail(NL_ERR_INVALID_ARG, "Unknown BITPIX value %d", bitpix);      // read.go:169
+    if (h->d_frames != h->d_frames_owned)
+        return fail(NL_ERR_INVALID_ARG, "upload_frame_fits: frames are attached, not owned");
+    const size_t bytes = (size_t)h->npix * (size_t)bpv;
+    int rc = ingest_reserve(h, bytes);
+    if (rc != NL_OK) return rc;
+    NL_HIP(hipMemcpyAsync(h->d_ingest, raw_host, bytes, hipMemcpyHostToDevice, h->stream));
+    const bool affine = !(multiplier == 1.0f && offset == 0.0f);
+    NL_HIP(nl::launch_fits_decode(h->d_ingest, bitpix, h->npix, bscale, bzero, affine, multiplier, offset,
+                                  h->d_frames + (int64_t)idx * h->npix, h->d_stat_partial, kStatBlocks,
+                                  h->stream));
+    if (stats_out) return decode_stats(h, h->npix, stats_out);
+    NL_HIP(hipStreamSynchronize(h->stream));          // the caller's buffer must not be read after return
+    return NL_OK;
+}
+
+int nl_stack_upload_frame_projected(nl_stack_t *h, int idx, const float *src_host, int src_w, int src_h,
+                                    const float trans[6], float out_of_bounds, float multiplier, float offset)
+{
+    NL_CHECK_HANDLE(h);
+    if (idx < 0 || idx >= h->n_frames || !src_host || !trans || src_w < 1 || src_h < 1)
+        return fail(NL_ERR_INVALID_ARG, "upload_frame_projected: bad argument (frame %d)", idx);
+    if (h->d_frames != h->d_frames_owned)
+        return fail(NL_ERR_INVALID_ARG, "upload_frame_projected: frames are attached, not owned");
+    float inv[6];
+    int rc = invert_transform(trans, inv);
+    if (rc != NL_OK) return rc;
+    const size_t bytes = (size_t)src_w * (size_t)src_h * sizeof(float);
+    rc = ingest_reserve(h, bytes);
+    if (rc != NL_OK) return rc;
+    NL_HIP(hipMemcpyAsync(h->d_ingest, src_host, bytes, hipMemcpyHostToDevice, h->stream));
+    const bool affine = !(multiplier == 1.0f && offset == 0.0f);
+    NL_HIP(nl::launch_project(static_cast<const float *>(h->d_ingest), src_w, src_h,
+                              h->d_frames + (int64_t)idx * h->npix, h->width, h->row0, h->rows, inv,
+                              out_of_bounds, affine, multiplier, offset, h->stream));
+    NL_HIP(hipStreamSynchronize(h->stream));
+    return NL_OK;
+}
+
+int nl_stack_frame_affine(nl_stack_t *h, int idx, float multiplier, float offset)
+{
+    NL_CHECK_HANDLE(h);
+    if (idx < 0 || idx >= h->n_frames) return fail(NL_ERR_INVALID_ARG, "frame_affine: bad index %d", idx);
+    NL_HIP(nl::launch_affine(h->d_frames + (int64_t)idx * h->npix, h->npix, multiplier, offset, h->stream));
+    NL_HIP(hipStreamSynchronize(h->stream));
+    return NL_OK;
+}
+
+int nl_stack_download_result_fits(nl_stack_t *h, void *raw_host)
+{
+    NL_CHECK_HANDLE(h);
+    if (!raw_host) return fail(NL_ERR_INVALID_ARG, "download_result_fits: null buffer");
+    if (h->pending) return fail(NL_ERR_INVALID_ARG, "download_result_fits: a pass is still pending (call nl_stack_finish)");
+    const size_t bytes = (size_t)h->npix * sizeof(float);
+    int rc = ingest_reserve(h, bytes);
+    if (rc != NL_OK) return rc;
+    NL_HIP(nl::launch_fits_encode(h->d_out, h->npix, 1, h->d_ingest, h->stream));
+    NL_HIP(hipMemcpyAsync(raw_host, h->d_ingest, bytes, hipMemcpyDeviceToHost, h->stream));
+    NL_HIP(hipStreamSynchronize(h->stream));
+    return NL_OK;
+}
+
+int nl_fits_decode(const void *raw_host, int bitpix, int64_t n, float bscale, float bzero, float *out_host,
+                   float *stats_out, int device)
+{
+    if (!raw_host || !out_host || n < 1 || n > 0x7fffffff)
+        return fail(NL_ERR_INVALID_ARG, "fits_decode: bad argument");
+    if (nl::fits_bytes_per_value(bitpix) == 0) return fail(NL_ERR_INVALID_ARG, "Unknown BITPIX value %d", bitpix);
+    // a one-frame handle of n x 1 pixels carries the stream and the scratch buffers
+    nl_stack_t *h = nl_stack_create(1, (int)n, 1, 0, 1, device);
+    if (!h) return NL_ERR_HIP;
+    int rc = nl_stack_upload_frame_fits(h, 0, raw_host, bitpix, bscale, bzero, 1.0f, 0.0f, stats_out);
+    if (rc == NL_OK) rc = nl_stack_download_tile(h, 0, out_host);
+    nl_stack_destroy(h);
+    return rc;
+}
+
+int nl_project_bilinear(const float *src_host, int src_w, int src_h, float *dst_host, int dst_w, int dst_h,
+                        const float trans[6], float out_of_bounds, int device)
+{
+    if (!src_host || !dst_host || dst_w < 1 || dst_h < 1)
+        return fail(NL_ERR_INVALID_ARG, "project_bilinear: bad argument");
+    nl_stack_t *h = nl_stack_create(1, dst_w, dst_h, 0, dst_h, device);
+    if (!h) return NL_ERR_HIP;
+    int rc = nl_stack_upload_frame_projected(h, 0, src_host, src_w, src_h, trans, out_of_bounds, 1.0f, 0.0f);
+    if (rc == NL_OK) rc = nl_stack_download_tile(h, 0, dst_host);
+    nl_stack_destroy(h);
+    return rc;
 }
 
 int nl_median_filter_3x3(const float *in_host, float *out_host, int width, int height, int device)

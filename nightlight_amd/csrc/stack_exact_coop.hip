@@ -7,8 +7,9 @@
 // cooperate on ONE pixel and still execute the reference's algorithm in the
 // reference's order, so every bit and both counters are unchanged:
 //   gather      stack.go:380-387   64 frames per step, order-preserving compaction (ballot + popcount)
-//   quickselect qsort.go:94-126    the two Hoare scans look at 64 elements at a time
-//                                  (ballot + find-first-set); swaps are single LDS writes
+//   quickselect qsort.go:94-126    a whole Hoare partition pass at once: the misplaced elements of
+//                                  both sides are listed with ballot + popcount and the pass's
+//                                  swaps are done in parallel (see coop_select)
 //   mean/stddev stats.go:246-261   the fp32 sums stay sequential (v_readlane feeds one add chain);
 //                                  differences and squares are computed 64 at a time
 //   winsorize   stack.go:646-672   the copy is clamped 64 samples at a time (ballot counts `changed`),
@@ -52,35 +53,66 @@ __device__ __forceinline__ float seq_sum(int n, F &&elem)
     return s;
 }
 
-// qsort.go:94-126 on a[0..n), k 1-based; all control values are wave-uniform
-__device__ float coop_select(float *a, int n, int k)
+// qsort.go:94-126 on a[0..n), k 1-based; all control values are wave-uniform.
+//
+// One Hoare partition pass (qsort.go:100-114) done by the whole wave at once.
+// Sequentially, l stops at the misplaced elements from the left (a >= pivot), r
+// at those from the right (a <= pivot), they are swapped pairwise and the pass
+// ends when the pointers meet.  Let L_0 < L_1 < ... be the positions with
+// a >= pivot and R_0 > R_1 > ... those with a <= pivot, both in the ORIGINAL
+// array.  By induction the i-th swap is exactly (L_i, R_i) as long as
+// L_i < R_i: the stretch between the pointers is still unmodified, and the
+// swapped-in values stop the opposite pointer no earlier than its own next
+// candidate (l_{i+1} = min(L_{i+1}, R_i), r_{i+1} = max(R_{i+1}, L_i)).  With
+// s = #{i : L_i < R_i} the pass performs the swaps i < s -- disjoint positions,
+// so they can be done in parallel -- and ends with r = max(R_s, L_{s-1}).
+// The resulting array is identical to the sequential one, element for element.
+__device__ float coop_select(float *a, int *lpos, int *rfwd, int n, int k)
 {
     const int lane = threadIdx.x;
+    const unsigned long long below = (1ull << lane) - 1ull;
     int left = 0, right = n - 1;
     while (left < right) {
         const float pivot = a[(left + right) >> 1];
-        int l = left - 1, r = right + 1;
-        for (;;) {
-            // do l++ while !(a[l] >= pivot)
-            for (int base = l + 1;; base += 64) {
-                const int idx = base + lane;
-                const float x = idx <= right ? a[idx] : __builtin_inff();
-                const unsigned long long m = __ballot(x >= pivot);
-                if (m) { l = base + __builtin_ctzll(m); break; }
-            }
-            // do r-- while !(a[r] <= pivot)
-            for (int base = r - 1;; base -= 64) {
-                const int idx = base - lane;
-                const float x = idx >= left ? a[idx] : -__builtin_inff();
-                const unsigned long long m = __ballot(x <= pivot);
-                if (m) { r = base - __builtin_ctzll(m); break; }
-            }
-            if (l >= r) break;
-            const float al = a[l], ar = a[r];
-            lds_fence();
-            if (lane == 0) { a[l] = ar; a[r] = al; }
-            lds_fence();
+        // classify, and list the misplaced positions in scan order
+        int nl = 0, nr = 0;
+        for (int base = left; base <= right; base += 64) {
+            const int idx = base + lane;
+            const bool in = idx <= right;
+            const float x = in ? a[idx] : 0.0f;
+            const bool isl = in && x >= pivot;
+            const bool isr = in && x <= pivot;
+            const unsigned long long ml = __ballot(isl), mr = __ballot(isr);
+            if (isl) lpos[nl + __popcll(ml & below)] = idx;
+            if (isr) rfwd[nr + __popcll(mr & below)] = idx;        // ascending; R_i = rfwd[nr-1-i]
+            nl += __popcll(ml);
+            nr += __popcll(mr);
         }
+        lds_fence();
+        // s = number of leading pairs with L_i < R_i (the predicate is monotone in i)
+        const int pairs = min(nl, nr);
+        int s_cnt = 0;
+        for (int base = 0; base < pairs; base += 64) {
+            const int i = base + lane;
+            const bool ok = i < pairs && lpos[i] < rfwd[nr - 1 - i];
+            const unsigned long long m = __ballot(ok);
+            s_cnt += __popcll(m);
+            if (m != ~0ull) break;
+        }
+        // the pass's swaps, all at once
+        for (int base = 0; base < s_cnt; base += 64) {
+            const int i = base + lane;
+            if (i < s_cnt) {
+                const int pl = lpos[i], pr = rfwd[nr - 1 - i];
+                const float xl = a[pl], xr = a[pr];
+                a[pl] = xr;
+                a[pr] = xl;
+            }
+        }
+        const int r_next = s_cnt < nr ? rfwd[nr - 1 - s_cnt] : -1;
+        const int l_prev = s_cnt > 0 ? lpos[s_cnt - 1] : -1;
+        const int r = max(r_next, l_prev);
+        lds_fence();
         const int offset = r - left + 1;
         if (k <= offset) {
             right = r;
@@ -93,10 +125,10 @@ __device__ float coop_select(float *a, int n, int k)
 }
 
 // qsort.go:68-82
-__device__ float coop_select_median(float *a, int n)
+__device__ float coop_select_median(float *a, int *lpos, int *rfwd, int n)
 {
     const int k = (n >> 1) + 1;
-    const float upper = coop_select(a, n, k);
+    const float upper = coop_select(a, lpos, rfwd, n, k);
     if (n & 1) return upper;
     // max of a[0..k-2]
     const int lane = threadIdx.x;
@@ -117,6 +149,8 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
 {
     extern __shared__ float a[];
     float *wz = a + p.n_frames;                   // winsorized copy (WINSOR only)
+    int *lpos = reinterpret_cast<int *>(a + (WINSOR ? 2 : 1) * p.n_frames);   // partition scratch, 2 x n_frames
+    int *rfwd = lpos + p.n_frames;
     const int lane = threadIdx.x;
     const int N = p.n_frames;
     int64_t limit = p.npix;
@@ -146,7 +180,7 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
         float res = p.ref_loc;
         if (n > 0) {
             for (;;) {
-                const float median = coop_select_median(a, n);
+                const float median = coop_select_median(a, lpos, rfwd, n);
                 lds_fence();
                 // stats.go:246-261
                 const float fn = (float)n;
@@ -230,8 +264,8 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
 int coop_supported(int mode, bool weighted, int n_frames)
 {
     if (weighted) return 0;
-    if (mode == NL_ST_SIGMA) return (size_t)n_frames * sizeof(float) <= 64 * 1024 ? 1 : 0;
-    if (mode == NL_ST_WINSOR_SIGMA) return (size_t)n_frames * 2 * sizeof(float) <= 64 * 1024 ? 1 : 0;
+    if (mode == NL_ST_SIGMA) return (size_t)n_frames * 3 * sizeof(float) <= 64 * 1024 ? 1 : 0;
+    if (mode == NL_ST_WINSOR_SIGMA) return (size_t)n_frames * 4 * sizeof(float) <= 64 * 1024 ? 1 : 0;
     return 0;
 }
 
@@ -240,10 +274,10 @@ hipError_t launch_stack_sigma_coop(int mode, const StackArgs &args, int grid, hi
     const size_t column = (size_t)args.n_frames * sizeof(float);
     if (mode == NL_ST_WINSOR_SIGMA) {
         *name = "stack_sigma_coop_kernel<true>";
-        hipLaunchKernelGGL(stack_sigma_coop_kernel<true>, dim3(grid), dim3(64), 2 * column, stream, args);
+        hipLaunchKernelGGL(stack_sigma_coop_kernel<true>, dim3(grid), dim3(64), 4 * column, stream, args);
     } else {
         *name = "stack_sigma_coop_kernel<false>";
-        hipLaunchKernelGGL(stack_sigma_coop_kernel<false>, dim3(grid), dim3(64), column, stream, args);
+        hipLaunchKernelGGL(stack_sigma_coop_kernel<false>, dim3(grid), dim3(64), 3 * column, stream, args);
     }
     return hipGetLastError();
 }

@@ -81,6 +81,17 @@ hipError_t launch_axpy(float *acc, const float *x, float weight, int first, int6
                        hipStream_t stream);
 hipError_t launch_scale(float *acc, float factor, int64_t n, hipStream_t stream);
 
+// ---- ingest.hip (FITS payload decode / encode, MatchHistogram, Project) ----
+int fits_bytes_per_value(int bitpix);
+hipError_t launch_fits_decode(const void *raw, int bitpix, int64_t n, float bscale, float bzero, bool affine,
+                              float mult, float off, float *out, double *partial /*[blocks][3]*/, int blocks,
+                              hipStream_t stream);
+hipError_t launch_fits_encode(const float *data, int64_t n, int replace_nans, void *raw, hipStream_t stream);
+hipError_t launch_affine(float *data, int64_t n, float mult, float off, hipStream_t stream);
+hipError_t launch_project(const float *src, int src_w, int src_h, float *dst, int dst_w, int row0, int rows,
+                          const float inv[6], float oob, bool affine, float mult, float off,
+                          hipStream_t stream);
+
 // ---- synth.hip ----
 hipError_t launch_fill_synthetic(float *frames, int64_t stride, int n_frames, int width,
                                  int height, int row0, int rows, uint64_t seed,

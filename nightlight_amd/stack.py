@@ -192,6 +192,56 @@ class StackHandle:
         return noise
 
 
+    # ---- formats and steps either side of the stack (include/nlstack.h, F3 / F4) ----
+    def upload_frame_fits(self, idx, raw, bitpix, bscale=1.0, bzero=0.0, multiplier=1.0, offset=0.0):
+        """Big-endian FITS payload bytes of this handle's tile -> frame slot idx,
+        decoded on the device; returns (min, max, mean) of the decoded tile."""
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        stats = np.zeros(3, np.float32)
+        capi.check(self._lib.nl_stack_upload_frame_fits(
+            self._h, int(idx), raw.ctypes.data_as(C.c_void_p), int(bitpix), float(bscale), float(bzero),
+            float(multiplier), float(offset), capi.fptr(stats)))
+        return stats
+
+    def upload_frame_projected(self, idx, src, src_w, src_h, trans, out_of_bounds=float("nan"),
+                               multiplier=1.0, offset=0.0):
+        src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1)
+        t = np.ascontiguousarray(trans, dtype=np.float32).reshape(6)
+        capi.check(self._lib.nl_stack_upload_frame_projected(
+            self._h, int(idx), capi.fptr(src), int(src_w), int(src_h), capi.fptr(t), float(out_of_bounds),
+            float(multiplier), float(offset)))
+
+    def frame_affine(self, idx, multiplier, offset):
+        capi.check(self._lib.nl_stack_frame_affine(self._h, int(idx), float(multiplier), float(offset)))
+
+    def download_result_fits(self):
+        raw = np.empty(self.tile_pixels * 4, np.uint8)
+        capi.check(self._lib.nl_stack_download_result_fits(self._h, raw.ctypes.data_as(C.c_void_p)))
+        return raw
+
+
+def fits_decode(raw, bitpix, bscale=1.0, bzero=0.0, device=0):
+    lib = capi.load()
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    bpv = {8: 1, 16: 2, 32: 4, 64: 8, -32: 4, -64: 8}.get(int(bitpix), 1)
+    n = raw.size // bpv
+    out = np.empty(n, np.float32)
+    stats = np.zeros(3, np.float32)
+    capi.check(lib.nl_fits_decode(raw.ctypes.data_as(C.c_void_p), int(bitpix), n, float(bscale),
+                                  float(bzero), capi.fptr(out), capi.fptr(stats), int(device)))
+    return out, stats
+
+
+def project_bilinear(src, src_w, src_h, dst_w, dst_h, trans, out_of_bounds=float("nan"), device=0):
+    lib = capi.load()
+    src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1)
+    t = np.ascontiguousarray(trans, dtype=np.float32).reshape(6)
+    dst = np.empty(int(dst_w) * int(dst_h), np.float32)
+    capi.check(lib.nl_project_bilinear(capi.fptr(src), int(src_w), int(src_h), capi.fptr(dst), int(dst_w),
+                                       int(dst_h), capi.fptr(t), float(out_of_bounds), int(device)))
+    return dst
+
+
 def weights_from_scalars(weighting, per_frame):
     """getWeights (stack.go:231-270) on per-frame exposure / noise / HFR."""
     lib = capi.load()

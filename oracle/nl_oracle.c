@@ -10,6 +10,7 @@
  */
 #include "nl_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
@@ -821,4 +822,160 @@ int nlo_find_sigmas_bisect(int mode, const float *const *lights, const float *we
         if (delta_h > 0) { high_left = high_mid; high_mid = 0.5f * (high_left + high_right); }
         else if (delta_h < 0) { high_right = high_mid; high_mid = 0.5f * (high_left + high_right); }
     }
+}
+
+
+/* ======================================================================== *
+ *  Formats and steps either side of the stack
+ * ======================================================================== */
+
+/* internal/fits/read.go:172-445 (readUint8Data ... readFloat64Data): every variant is
+ * "assemble the big-endian value, v = float32(val)*Bscale + Bzero, track min / max,
+ * sum in float64 in file order"; mean = float32(sum / n) (:210, :255, ...). */
+int nlo_fits_decode(const unsigned char *raw, int bitpix, int64_t n, float bscale, float bzero,
+                    float *out, float *min, float *max, float *mean)
+{
+    float mn = FLT_MAX, mx = -FLT_MAX;
+    double sum = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        float val;
+        switch (bitpix) {
+        case 8:
+            val = (float)raw[i];                                                   /* :192-193 */
+            break;
+        case 16: {
+            const unsigned char *b = raw + 2 * i;
+            int16_t x = (int16_t)(uint16_t)(((uint16_t)b[0] << 8) | (uint16_t)b[1]); /* :234 */
+            val = (float)x;
+            break;
+        }
+        case 32: {
+            const unsigned char *b = raw + 4 * i;
+            uint32_t u = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | (uint32_t)b[3];
+            val = (float)(int32_t)u;
+            break;
+        }
+        case 64: {
+            const unsigned char *b = raw + 8 * i;
+            uint64_t u = 0;
+            for (int j = 0; j < 8; j++) u = (u << 8) | (uint64_t)b[j];            /* :325-326 */
+            val = (float)(int64_t)u;
+            break;
+        }
+        case -32: {
+            const unsigned char *b = raw + 4 * i;
+            uint32_t u = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | (uint32_t)b[3];
+            memcpy(&val, &u, 4);                                                   /* :372-373 */
+            break;
+        }
+        case -64: {
+            const unsigned char *b = raw + 8 * i;
+            uint64_t u = 0;
+            double d;
+            for (int j = 0; j < 8; j++) u = (u << 8) | (uint64_t)b[j];
+            memcpy(&d, &u, 8);
+            val = (float)d;                                                        /* :421-423 */
+            break;
+        }
+        default:
+            return -1;                                                             /* :169 */
+        }
+        float t = val * bscale;
+        float v = t + bzero;
+        if (v < mn) mn = v;
+        if (v > mx) mx = v;
+        sum += (double)v;
+        out[i] = v;
+    }
+    if (min) *min = mn;
+    if (max) *max = mx;
+    if (mean) *mean = (float)(sum / (double)n);
+    return 0;
+}
+
+/* internal/fits/write.go:182-200 */
+void nlo_fits_encode(const float *data, int64_t n, int replace_nans, unsigned char *raw)
+{
+    for (int64_t i = 0; i < n; i++) {
+        float d = data[i];
+        if (replace_nans && d != d) d = 0.0f;
+        uint32_t u;
+        memcpy(&u, &d, 4);
+        raw[4 * i + 0] = (unsigned char)(u >> 24);
+        raw[4 * i + 1] = (unsigned char)(u >> 16);
+        raw[4 * i + 2] = (unsigned char)(u >> 8);
+        raw[4 * i + 3] = (unsigned char)u;
+    }
+}
+
+/* internal/fits/pixelops.go:601-605 */
+void nlo_affine(float *data, int64_t n, float multiplier, float offset)
+{
+    for (int64_t i = 0; i < n; i++) {
+        float t = data[i] * multiplier;
+        data[i] = t + offset;
+    }
+}
+
+/* internal/star/coord.go:159-199 */
+int nlo_transform_invert(const float t[6], float inv[6])
+{
+    const float A = t[0], B = t[1], C = t[2], D = t[3], E = t[4], F = t[5];
+    float bd = B * D, ae = A * E;
+    float eps = bd - ae;
+    if (eps < 1e-8f && -eps < 1e-8f) return -1;
+    float den1 = bd - ae;                 /* b*d - a*e */
+    float den2 = ae - bd;                 /* a*e - b*d */
+    float ce = C * E, bf = B * F, cd = C * D, af = A * F;
+    inv[0] = -E / den1;
+    inv[1] = B / den1;
+    inv[2] = (ce - bf) / den1;
+    inv[3] = -D / den2;
+    inv[4] = A / den2;
+    inv[5] = (cd - af) / den2;
+    return 0;
+}
+
+/* internal/fits/project.go:26-76 with Transform2D.Apply (coord.go:141-145).
+ * int32(math.Floor(x)) of a value outside the int32 range (or NaN) is 0x80000000 on
+ * amd64, i.e. negative, i.e. out of bounds: the range test below says the same. */
+int nlo_project_bilinear(const float *src, int32_t src_w, int32_t src_h,
+                         float *dst, int32_t dst_w, int32_t dst_h,
+                         const float trans[6], float out_of_bounds)
+{
+    float inv[6];
+    if (nlo_transform_invert(trans, inv) != 0) return -1;
+    for (int32_t row = 0; row < dst_h; row++) {
+        for (int32_t col = 0; col < dst_w; col++) {
+            float px = (float)col, py = (float)row;
+            float ax = inv[0] * px, bx = inv[1] * py;
+            float sx = ax + bx;
+            float X = sx + inv[2];
+            float ay = inv[3] * px, by = inv[4] * py;
+            float sy = ay + by;
+            float Y = sy + inv[5];
+            double fx = floor((double)X), fy = floor((double)Y);
+            int ok = fx >= 0.0 && fy >= 0.0 && fx < 2147483647.0 && fy < 2147483647.0;
+            int32_t xl = 0, yl = 0;
+            if (ok) {
+                xl = (int32_t)fx;
+                yl = (int32_t)fy;
+                if (xl + 1 >= src_w || yl + 1 >= src_h) ok = 0;
+            }
+            if (!ok) {
+                dst[(int64_t)col + (int64_t)row * dst_w] = out_of_bounds;
+                continue;
+            }
+            float xr = X - (float)xl, yr = Y - (float)yl;
+            int64_t xlyl = (int64_t)xl + (int64_t)yl * src_w;
+            float omx = 1.0f - xr, omy = 1.0f - yr;
+            float p0 = src[xlyl] * omx, p1 = src[xlyl + 1] * xr;
+            float vyl = p0 + p1;
+            float p2 = src[xlyl + src_w] * omx, p3 = src[xlyl + src_w + 1] * xr;
+            float vyh = p2 + p3;
+            float q0 = vyl * omy, q1 = vyh * yr;
+            dst[(int64_t)col + (int64_t)row * dst_w] = q0 + q1;
+        }
+    }
+    return 0;
 }

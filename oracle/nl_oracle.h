@@ -143,6 +143,22 @@ int  nlo_find_sigmas_bisect(int mode, const float *const *lights, const float *w
                             float *res, int64_t *clip_low, int64_t *clip_high,
                             float *sigma_low, float *sigma_high);
 
+/* ---- the formats and steps either side of the stack (F3, F4) ----
+ * internal/fits/read.go:172-445   FITS payload -> fp32: big-endian BITPIX 8/16/32/64/-32/-64,
+ *                                 v = float32(val)*BSCALE + BZERO; min, max, mean (fp64 sum, in order)
+ * internal/fits/write.go:182-200  fp32 -> big-endian bytes, NaN -> 0
+ * internal/fits/pixelops.go:601-605  MatchHistogram: x*multiplier + offset, in place
+ * internal/star/coord.go:141-145, :159-199  Transform2D.Apply / Invert
+ * internal/fits/project.go:26-76  bilinear resampling, out of bounds -> given value (NaN) */
+int  nlo_fits_decode(const unsigned char *raw, int bitpix, int64_t n, float bscale, float bzero,
+                     float *out, float *min, float *max, float *mean);
+void nlo_fits_encode(const float *data, int64_t n, int replace_nans, unsigned char *raw);
+void nlo_affine(float *data, int64_t n, float multiplier, float offset);
+int  nlo_transform_invert(const float t[6], float inv[6]);
+int  nlo_project_bilinear(const float *src, int32_t src_w, int32_t src_h,
+                          float *dst, int32_t dst_w, int32_t dst_h,
+                          const float trans[6], float out_of_bounds);
+
 #ifdef __cplusplus
 }
 #endif

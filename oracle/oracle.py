@@ -85,6 +85,17 @@ def lib():
                                       C.c_float, C.c_float, C.c_int, _f32p, _i64p, _i64p,
                                       C.POINTER(C.c_int)]
         L.nlo_stack_apply.restype = C.c_int
+        _u8p = C.POINTER(C.c_ubyte)
+        L.nlo_fits_decode.argtypes = [_u8p, C.c_int, C.c_int64, C.c_float, C.c_float, _f32p, _f32p, _f32p, _f32p]
+        L.nlo_fits_decode.restype = C.c_int
+        L.nlo_fits_encode.argtypes = [_f32p, C.c_int64, C.c_int, _u8p]
+        L.nlo_fits_encode.restype = None
+        L.nlo_affine.argtypes = [_f32p, C.c_int64, C.c_float, C.c_float]
+        L.nlo_affine.restype = None
+        L.nlo_transform_invert.argtypes = [_f32p, _f32p]
+        L.nlo_transform_invert.restype = C.c_int
+        L.nlo_project_bilinear.argtypes = [_f32p, C.c_int32, C.c_int32, _f32p, C.c_int32, C.c_int32, _f32p, C.c_float]
+        L.nlo_project_bilinear.restype = C.c_int
         L.nlo_stack_incremental.argtypes = [_f32p, _f32p, C.c_int64, C.c_float, C.c_int]
         L.nlo_stack_incremental.restype = None
         L.nlo_stack_incremental_finalize.argtypes = [_f32p, C.c_int64, C.c_float]
@@ -245,3 +256,50 @@ def find_sigmas_bisect(mode, frames, clip_perc_low, clip_perc_high, weights=None
                                           int(num_cpu), _fp(res), C.byref(cl), C.byref(ch),
                                           C.byref(sl), C.byref(sh))
     return passes, res, cl.value, ch.value, np.float32(sl.value), np.float32(sh.value)
+
+
+# ---- fits/read.go, fits/write.go, fits/pixelops.go, fits/project.go ---------------
+BYTES_PER_VALUE = {8: 1, 16: 2, 32: 4, 64: 8, -32: 4, -64: 8}
+
+
+def fits_decode(raw, bitpix, bscale=1.0, bzero=0.0):
+    """raw: bytes / uint8 array of a big-endian FITS payload -> (rc, fp32 data, min, max, mean)."""
+    raw = np.ascontiguousarray(np.frombuffer(bytes(raw), np.uint8) if not isinstance(raw, np.ndarray) else raw,
+                               np.uint8)
+    if bitpix not in BYTES_PER_VALUE:
+        return -1, None, 0.0, 0.0, 0.0
+    n = raw.size // BYTES_PER_VALUE[bitpix]
+    out = np.empty(n, np.float32)
+    mn, mx, mean = C.c_float(), C.c_float(), C.c_float()
+    rc = lib().nlo_fits_decode(raw.ctypes.data_as(C.POINTER(C.c_ubyte)), int(bitpix), n, float(bscale),
+                               float(bzero), _fp(out), C.byref(mn), C.byref(mx), C.byref(mean))
+    return rc, out, mn.value, mx.value, mean.value
+
+
+def fits_encode(data, replace_nans=True):
+    data = _f32(data).reshape(-1)
+    raw = np.empty(data.size * 4, np.uint8)
+    lib().nlo_fits_encode(_fp(data), data.size, int(bool(replace_nans)), raw.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return raw
+
+
+def affine(data, multiplier, offset):
+    out = _f32(data).reshape(-1).copy()
+    lib().nlo_affine(_fp(out), out.size, float(multiplier), float(offset))
+    return out
+
+
+def transform_invert(trans):
+    t = _f32(trans).reshape(6)
+    inv = np.zeros(6, np.float32)
+    rc = lib().nlo_transform_invert(_fp(t), _fp(inv))
+    return rc, inv
+
+
+def project_bilinear(src, src_w, src_h, dst_w, dst_h, trans, out_of_bounds=np.nan):
+    src = _f32(src).reshape(-1)
+    t = _f32(trans).reshape(6)
+    dst = np.empty(int(dst_w) * int(dst_h), np.float32)
+    rc = lib().nlo_project_bilinear(_fp(src), int(src_w), int(src_h), _fp(dst), int(dst_w), int(dst_h),
+                                    _fp(t), float(out_of_bounds))
+    return rc, dst

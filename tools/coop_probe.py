@@ -4,7 +4,8 @@ dense tiles, to separate per-pixel work from the scattered-list effects."""
 import sys
 import time
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nightlight_amd.stack import StackHandle
 
 for n, w, h in ((128, 4096, 4), (128, 4096, 64), (512, 4096, 4), (512, 4096, 16), (512, 4096, 64)):

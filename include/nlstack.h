@@ -80,6 +80,13 @@ void nl_stack_destroy(nl_stack_t *h);
 int nl_stack_upload_frame(nl_stack_t *h, int idx, const float *host_frame);
 /* Same, but the host buffer holds only the tile (rows*width floats). */
 int nl_stack_upload_tile(nl_stack_t *h, int idx, const float *host_tile);
+/* Overlapped upload (caller side of the path, OpStackBatches' frame loop,
+ * internal/ops/stack/stackbatches.go:68-96): the frame's tile is copied into a
+ * pinned staging buffer and the call returns -- host_frame is not retained --
+ * while the DMA proceeds on a copy stream.  The next nl_stack_run* waits for
+ * the uploads on the device; nl_stack_upload_wait waits on the host. */
+int nl_stack_upload_frame_async(nl_stack_t *h, int idx, const float *host_frame);
+int nl_stack_upload_wait(nl_stack_t *h);
 /* Device address of the planar frame buffer (for in-place producers that
  * already live on the GPU); valid until destroy/attach. */
 void *nl_stack_frames_device_ptr(nl_stack_t *h);

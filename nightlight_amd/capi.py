@@ -30,7 +30,7 @@ ERR_NO_DEVICE = -9
 EXPORTS = [
     "nl_last_error", "nl_device_count", "nl_version",
     "nl_stack_create", "nl_stack_destroy",
-    "nl_stack_upload_frame", "nl_stack_upload_tile", "nl_stack_frames_device_ptr",
+    "nl_stack_upload_frame", "nl_stack_upload_tile", "nl_stack_upload_frame_async", "nl_stack_upload_wait", "nl_stack_frames_device_ptr",
     "nl_stack_attach_device_frames", "nl_stack_fill_synthetic", "nl_stack_download_tile",
     "nl_stack_set_weights", "nl_weights_from_scalars",
     "nl_stack_run", "nl_stack_run_async", "nl_stack_finish", "nl_stack_result_device_ptr",
@@ -114,6 +114,8 @@ def load():
     L.nl_stack_frame_noise.argtypes = [vp, C.c_int, _f32p]
     L.nl_stack_weights_from_noise.argtypes = [vp, _f32p]
     L.nl_median_filter_3x3.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int]
+    L.nl_stack_upload_frame_async.argtypes = [vp, C.c_int, _f32p]
+    L.nl_stack_upload_wait.argtypes = [vp]
     L.nl_stack_upload_frame_fits.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, C.c_float,
                                              C.c_float, _f32p]
     L.nl_stack_upload_frame_projected.argtypes = [vp, C.c_int, _f32p, C.c_int, C.c_int, _f32p, C.c_float,

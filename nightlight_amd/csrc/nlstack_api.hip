@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "stack_kernels.h"
@@ -37,6 +38,8 @@ int fail(int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                \
     } while (0)
 
+constexpr int kStageSlots = 4;      // pinned staging buffers of the asynchronous upload
+constexpr int kStageThreads = 4;    // host threads filling one staging buffer
 constexpr int kStatBlocks = 2048;
 constexpr int kListGrid = 2048;     // workgroups of the exact kernel in fallback-list mode
 constexpr int kCoopGrid = 16384;    // workgroups (one wave each) of the wave-per-pixel exact replay
@@ -78,6 +81,13 @@ struct nl_stack {
     double *d_stat_partial = nullptr;          // [kStatBlocks*3]
     void *d_ingest = nullptr;                  // raw FITS bytes / unaligned source frame, grown on demand
     size_t ingest_bytes = 0;
+    // asynchronous uploads: pinned staging ring + copy stream (nl_stack_upload_frame_async)
+    hipStream_t copy_stream = nullptr;
+    void *h_stage[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t stage_done[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool stage_used[kStageSlots] = {false, false, false, false};
+    int stage_next = 0;
+    bool uploads_pending = false;
     int max_grid = 0;
     int last_mode = -1;
     bool last_has_counters = false;
@@ -115,6 +125,12 @@ static int destroy_impl(nl_stack_t *h)
     if (h->d_counters) (void)hipFree(h->d_counters);
     if (h->d_stat_partial) (void)hipFree(h->d_stat_partial);
     if (h->d_ingest) (void)hipFree(h->d_ingest);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    for (int i = 0; i < kStageSlots; i++) {
+        if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
+        if (h->stage_done[i]) (void)hipEventDestroy(h->stage_done[i]);
+    }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
     if (h->ev_dom0) (void)hipEventDestroy(h->ev_dom0);
@@ -205,6 +221,16 @@ nl_stack_t *nl_stack_create(int n_frames, int width, int height, int row0, int r
         NL_HIP(hipSetDevice((h)->device));                              \
     } while (0)
 
+// entry points that read frames on h->stream outside a stack pass first let pending
+// asynchronous uploads land
+#define NL_SETTLE_UPLOADS(h)                                            \
+    do {                                                                \
+        if ((h)->uploads_pending) {                                     \
+            NL_HIP(hipStreamSynchronize((h)->copy_stream));             \
+            (h)->uploads_pending = false;                               \
+        }                                                               \
+    } while (0)
+
 int nl_stack_upload_frame(nl_stack_t *h, int idx, const float *host_frame)
 {
     NL_CHECK_HANDLE(h);
@@ -224,9 +250,61 @@ int nl_stack_upload_tile(nl_stack_t *h, int idx, const float *host_tile)
     return NL_OK;
 }
 
+// Overlapped uploads (the caller side of the path).  The
+// caller's frame is copied into a pinned staging buffer by a few host threads
+// and this call returns (the caller's pointer is not retained, cgo rules); the
+// DMA runs on its own stream while the caller prepares the next frame, and the
+// next stack pass waits for it on the device, not on the host.
+int nl_stack_upload_frame_async(nl_stack_t *h, int idx, const float *host_frame)
+{
+    NL_CHECK_HANDLE(h);
+    if (idx < 0 || idx >= h->n_frames || !host_frame)
+        return fail(NL_ERR_INVALID_ARG, "upload_frame_async: bad index %d or null frame", idx);
+    if (h->d_frames != h->d_frames_owned)
+        return fail(NL_ERR_INVALID_ARG, "upload_frame_async: frames are attached, not owned");
+    const size_t bytes = (size_t)h->npix * sizeof(float);
+    if (!h->copy_stream) NL_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    const int slot = h->stage_next;
+    h->stage_next = (slot + 1) % kStageSlots;
+    if (!h->h_stage[slot]) {
+        NL_HIP(hipHostMalloc(&h->h_stage[slot], bytes, hipHostMallocDefault));
+        NL_HIP(hipEventCreateWithFlags(&h->stage_done[slot], hipEventDisableTiming));
+    }
+    if (h->stage_used[slot]) NL_HIP(hipEventSynchronize(h->stage_done[slot]));     // its last DMA has left the buffer
+    const char *src = reinterpret_cast<const char *>(host_frame + (int64_t)h->row0 * h->width);
+    char *dst = static_cast<char *>(h->h_stage[slot]);
+    if (bytes < ((size_t)4 << 20)) {
+        memcpy(dst, src, bytes);
+    } else {
+        std::thread workers[kStageThreads - 1];
+        const size_t part = (bytes / kStageThreads + 63) & ~(size_t)63;
+        for (int t = 1; t < kStageThreads; t++) {
+            const size_t b = (size_t)t * part, e = (b + part < bytes) ? b + part : bytes;
+            workers[t - 1] = std::thread([=] { if (b < e) memcpy(dst + b, src + b, e - b); });
+        }
+        memcpy(dst, src, part < bytes ? part : bytes);
+        for (auto &w : workers) w.join();
+    }
+    NL_HIP(hipMemcpyAsync(h->d_frames + (int64_t)idx * h->npix, dst, bytes, hipMemcpyHostToDevice, h->copy_stream));
+    NL_HIP(hipEventRecord(h->stage_done[slot], h->copy_stream));
+    h->stage_used[slot] = true;
+    h->uploads_pending = true;
+    return NL_OK;
+}
+
+// Host-side wait for every asynchronous upload issued so far.
+int nl_stack_upload_wait(nl_stack_t *h)
+{
+    NL_CHECK_HANDLE(h);
+    if (h->copy_stream) NL_HIP(hipStreamSynchronize(h->copy_stream));
+    h->uploads_pending = false;
+    return NL_OK;
+}
+
 int nl_stack_download_tile(nl_stack_t *h, int idx, float *host_tile)
 {
     NL_CHECK_HANDLE(h);
+    NL_SETTLE_UPLOADS(h);
     if (idx < 0 || idx >= h->n_frames || !host_tile)
         return fail(NL_ERR_INVALID_ARG, "download_tile: bad index %d or null tile", idx);
     NL_HIP(hipMemcpyAsync(host_tile, h->d_frames + (int64_t)idx * h->npix,
@@ -323,6 +401,13 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
     if (mode == NL_ST_MAD_SIGMA && weighted)
         return fail(NL_ERR_WEIGHTED_MAD, "MADSigma stacking with weights is still unimplemented");
     if (mode == NL_ST_LINEAR_FIT || mode == NL_ST_MEDIAN) weighted = false;  // stack.go:158,188-189
+
+    if (h->uploads_pending) {
+        // asynchronous uploads: the pass waits for the last DMA on the device
+        const int last = (h->stage_next + kStageSlots - 1) % kStageSlots;
+        NL_HIP(hipStreamWaitEvent(h->stream, h->stage_done[last], 0));
+        h->uploads_pending = false;
+    }
 
     nl::StackArgs a;
     a.frames = h->d_frames;
@@ -611,6 +696,7 @@ int nl_stack_frame_stats(nl_stack_t *h, int idx, float *mn, float *mean, float *
                          double *variance)
 {
     NL_CHECK_HANDLE(h);
+    NL_SETTLE_UPLOADS(h);
     if (idx < 0 || idx >= h->n_frames) return fail(NL_ERR_INVALID_ARG, "frame_stats: bad index %d", idx);
     return frame_stats_impl(h, h->d_frames + (int64_t)idx * h->npix, h->npix, mn, mean, mx, variance);
 }
@@ -636,6 +722,7 @@ static int frame_noise_impl(nl_stack_t *h, const float *d, float *noise)
 int nl_stack_frame_noise(nl_stack_t *h, int idx, float *noise)
 {
     NL_CHECK_HANDLE(h);
+    NL_SETTLE_UPLOADS(h);
     if (idx < 0 || idx >= h->n_frames || !noise)
         return fail(NL_ERR_INVALID_ARG, "frame_noise: bad index %d or null output", idx);
     if (h->row0 != 0 || h->rows != h->height)
@@ -756,6 +843,7 @@ int nl_stack_upload_frame_projected(nl_stack_t *h, int idx, const float *src_hos
 int nl_stack_frame_affine(nl_stack_t *h, int idx, float multiplier, float offset)
 {
     NL_CHECK_HANDLE(h);
+    NL_SETTLE_UPLOADS(h);
     if (idx < 0 || idx >= h->n_frames) return fail(NL_ERR_INVALID_ARG, "frame_affine: bad index %d", idx);
     NL_HIP(nl::launch_affine(h->d_frames + (int64_t)idx * h->npix, h->npix, multiplier, offset, h->stream));
     NL_HIP(hipStreamSynchronize(h->stream));

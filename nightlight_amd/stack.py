@@ -54,6 +54,15 @@ class StackHandle:
         assert frame.size == self.width * self.height
         capi.check(self._lib.nl_stack_upload_frame(self._h, int(idx), capi.fptr(frame)))
 
+    def upload_frame_async(self, idx, frame):
+        """Overlapped upload through the pinned staging ring (frame = whole image)."""
+        frame = np.ascontiguousarray(frame, dtype=np.float32).reshape(-1)
+        assert frame.size == self.width * self.height
+        capi.check(self._lib.nl_stack_upload_frame_async(self._h, int(idx), capi.fptr(frame)))
+
+    def upload_wait(self):
+        capi.check(self._lib.nl_stack_upload_wait(self._h))
+
     def upload_tile(self, idx, tile):
         tile = np.ascontiguousarray(tile, dtype=np.float32).reshape(-1)
         assert tile.size == self.tile_pixels

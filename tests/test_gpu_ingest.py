@@ -138,3 +138,26 @@ def test_align_and_stack_tiles(nl, oracle):
             th += ch
     assert same_values(out, want) and (tl, th) == (wl, wh)
     assert np.isnan(np.stack(aligned)).any()
+
+
+def test_async_uploads_overlap_and_match_the_blocking_path(nl, oracle):
+    # pinned staging ring (4 slots) + copy stream: more frames than slots, buffers reused and
+    # overwritten on the host right after each call (the pointer must not be retained)
+    width, height, n = 160, 96, 11
+    frames = make_frames(n, width, height, seed=31)
+    out = np.zeros(width * height, np.float32)
+    tl = th = 0
+    for row0, rows in ((0, 50), (50, 46)):
+        with nl.StackHandle(n, width, height, row0=row0, rows=rows) as st:
+            scratch = np.empty(width * height, np.float32)
+            for k in range(n):
+                scratch[:] = frames[k].reshape(-1)
+                st.upload_frame_async(k, scratch)
+                scratch[:] = -1.0                      # caller reuses its buffer immediately
+            st.set_exact(True)
+            _, cl, ch = st.run(2, 2.5, 2.5, out=out)   # waits for the DMAs on the device
+            tl += cl
+            th += ch
+            assert same_values(st.download_tile(n - 1), frames[n - 1].reshape(-1)[row0 * width:(row0 + rows) * width])
+    rc, want, wl, wh, _ = oracle.stack_apply(2, frames, None, 2.5, 2.5)
+    assert same_values(out, want) and (tl, th) == (wl, wh)

@@ -100,6 +100,61 @@ __device__ __forceinline__ void sort_network(float (&v)[NS])
     });
 }
 
+// The zonal kernels need exact ranks only at the ends (clip zones) and around
+// the middle (median window) of the sorted column: positions [0,E0), [E1,E2)
+// and [E3,NS).  The two stretches in between are only ever summed, so they
+// merely have to hold the right SET of samples.  Walking the network backwards,
+// a comparator is dropped if both its wires end in the same such stretch and
+// no later kept comparator touches either wire: it could only swap two values
+// inside the stretch.  (1313 of 1471 comparators remain for NS = 128.)
+template <int NS, int E0, int E1, int E2, int E3>
+struct ZonalNetwork {
+    using Full = OemNetwork<NS>;
+    static constexpr int stretch(int i) { return i < E0 ? 0 : (i < E1 ? 1 : (i < E2 ? 0 : (i < E3 ? 2 : 0))); }
+    struct Table { CePair e[Full::kCount > 0 ? Full::kCount : 1]; int n; };
+    static constexpr Table make()
+    {
+        Table t{};
+        bool touched[NS] = {};
+        bool keep[Full::kCount > 0 ? Full::kCount : 1] = {};
+        for (int c = Full::kCount - 1; c >= 0; c--) {
+            const CePair ce = Full::kTable.e[c];
+            const int sl = stretch(ce.lo), sh = stretch(ce.hi);
+            if (sl == sh && sl != 0 && !touched[ce.lo] && !touched[ce.hi]) continue;
+            keep[c] = true;
+            touched[ce.lo] = true;
+            touched[ce.hi] = true;
+        }
+        int n = 0;
+        for (int c = 0; c < Full::kCount; c++)
+            if (keep[c]) t.e[n++] = Full::kTable.e[c];
+        t.n = n;
+        return t;
+    }
+    static constexpr Table kTable = make();
+    static constexpr int kCount = kTable.n;
+};
+
+struct FullSort {
+    template <int NS>
+    static __device__ __forceinline__ void apply(float (&v)[NS]) { sort_network<NS>(v); }
+};
+template <int E0, int E1, int E2, int E3>
+struct ZonalSort {
+    template <int NS>
+    static __device__ __forceinline__ void apply(float (&v)[NS])
+    {
+        using Net = ZonalNetwork<NS, E0, E1, E2, E3>;
+        static_chunks<0, Net::kCount, 64>([&](auto I) NL_INL {
+            constexpr CePair ce = Net::kTable.e[decltype(I)::value];
+            const float lo = fminf(v[ce.lo], v[ce.hi]);
+            const float hi = fmaxf(v[ce.lo], v[ce.hi]);
+            v[ce.lo] = lo;
+            v[ce.hi] = hi;
+        });
+    }
+};
+
 // the compiler must not share the 'rank in [a,b)' masks between passes: 128
 // live lane masks would spill the SGPR file
 __device__ __forceinline__ int opaque(int x)
@@ -138,7 +193,8 @@ __device__ __forceinline__ float nan_to_inf(float x)
 // each); the frame pointer advances by one frame per position and stops at the
 // last frame, so unused positions re-read a valid address.
 // GAP: the caller guarantees N > NS - GAP (distance to its next smaller network size).
-template <int NS, int GAP = 16>
+// SORT: FullSort, or ZonalSort<...> where only part of the order is needed.
+template <int NS, int GAP = 16, class SORT = FullSort>
 __device__ __forceinline__ int gather_sorted(const float *frames, int64_t stride, int N,
                                              unsigned boff, float (&v)[NS])
 {
@@ -190,7 +246,7 @@ __device__ __forceinline__ int gather_sorted(const float *frames, int64_t stride
         constexpr int k = decltype(K)::value;
         v[k] = nan_to_inf(v[k]);
     });
-    sort_network<NS>(v);
+    SORT::template apply<NS>(v);
     return NS - nan_cnt;
 }
 

@@ -93,8 +93,12 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
 
         // A genuine +-Inf sample stays among the n valid ones, makes the variance
         // non-finite and thereby sends the pixel to the exact kernel (`bail`).
+        // zonal sigma: only the clip zones and the median window need exact ranks (the
+        // winsorized variant also reads single positions in between: full sort)
+        constexpr int MW0 = ZONAL ? ZH / 2 - 1 : 0, MW1 = ZONAL ? ZL + NS / 2 + 1 : NS;
+        using Sorter = std::conditional_t<ZONAL && !WINSOR, ZonalSort<ZL, MW0, MW1, ZH>, FullSort>;
         float v[NS];
-        const int n = gather_sorted<NS>(p.frames, p.stride, N, boff, v);
+        const int n = gather_sorted<NS, 16, Sorter>(p.frames, p.stride, N, boff, v);
         bool to_exact = false;
 
         float res = p.ref_loc;

@@ -45,7 +45,7 @@ constexpr int kListGrid = 2048;     // workgroups of the exact kernel in fallbac
 constexpr int kCoopGrid = 16384;    // workgroups (one wave each) of the wave-per-pixel exact replay
 constexpr int kListLanes = 4;       // pixels per wave there: few pixels, keep divergence low
 // per-pass device scratch, zeroed by one memset: clip accumulators + the two list lengths
-constexpr size_t kScratchBytes = sizeof(unsigned long long) * (2 * nl::kClipSlots + 1);
+constexpr size_t kScratchBytes = sizeof(unsigned long long) * (2 * nl::kClipSlots + 2);   // + list lengths + snapshot
 
 int next_pow2(int n)
 {
@@ -63,6 +63,8 @@ struct nl_stack {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;      // whole pass
     hipEvent_t ev_dom0 = nullptr, ev_dom1 = nullptr;        // dominant kernel only
+    hipStream_t side_stream = nullptr;                     // replay of the dominant kernel's hand-overs,
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;        // concurrent with the generic pass
     float *d_frames_owned = nullptr;  // [n_frames][npix]
     float *d_frames = nullptr;        // owned or lent
     float *d_out = nullptr;           // [npix]
@@ -135,6 +137,10 @@ static int destroy_impl(nl_stack_t *h)
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
     if (h->ev_dom0) (void)hipEventDestroy(h->ev_dom0);
     if (h->ev_dom1) (void)hipEventDestroy(h->ev_dom1);
+    if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return NL_OK;
@@ -157,6 +163,9 @@ static int create_impl(nl_stack_t *h)
     NL_HIP(hipEventCreate(&h->ev_stop));
     NL_HIP(hipEventCreate(&h->ev_dom0));
     NL_HIP(hipEventCreate(&h->ev_dom1));
+    NL_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    NL_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    NL_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     const size_t frame_bytes = (size_t)h->npix * sizeof(float);
     NL_HIP(hipMalloc(&h->d_frames_owned, frame_bytes * (size_t)h->n_frames));
     h->d_frames = h->d_frames_owned;
@@ -424,6 +433,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
     a.list = nullptr;
     a.list_count = nullptr;
     a.list_capacity = 0;
+    a.list_begin = nullptr;
 
     NL_HIP(hipEventRecord(h->ev_start, h->stream));
     NL_HIP(hipMemsetAsync(h->d_partial, 0, kScratchBytes, h->stream));
@@ -475,21 +485,44 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         f.in_list = nullptr;
         f.in_count = nullptr;
         f.in_capacity = 0;
-        int fast_grid = 0;
-        if (a.n_frames <= 128)
-            NL_HIP(nl::launch_stack_sigma_fast(a, f, &fast_grid, h->stream, &h->last_kernel, h->ev_dom1,
-                                               mode == NL_ST_WINSOR_SIGMA));
-        else   // 129..512 frames: 2 or 4 lanes per pixel
-            NL_HIP(nl::launch_stack_sigma_ml(a, f, h->stream, &h->last_kernel, h->ev_dom1,
-                                             mode == NL_ST_WINSOR_SIGMA));
-        // exact replay of the undecidable pixels: one wave per pixel where available
+        // exact replay of the undecidable pixels: one wave per pixel where available.  The
+        // hand-overs of the dominant kernel are replayed on a side stream WHILE the generic
+        // pass runs (both only depend on the dominant kernel); what the generic pass adds
+        // to the list is replayed after it.
         nl::StackArgs e = a;
         e.list = h->d_fb_list;
         e.list_count = h->d_fb_count;
         e.list_capacity = (unsigned)h->npix;
+        const bool coop = nl::coop_supported(mode, weighted, a.n_frames) != 0;
+        unsigned *snap = h->d_fb_count + 2;               // list length when the dominant kernel is done
+        struct Fork { nl_stack *h; nl::StackArgs e; int mode; unsigned *snap; hipError_t err; } fork{h, e, mode, snap, hipSuccess};
+        nl::AfterDominant after = nullptr;
+        if (coop) after = [](void *u) {
+            Fork *k = static_cast<Fork *>(u);
+            nl_stack *hh = k->h;
+            const char *ignored = "";
+            hipError_t err = hipMemcpyAsync(k->snap, hh->d_fb_count, sizeof(unsigned), hipMemcpyDeviceToDevice, hh->stream);
+            if (err == hipSuccess) err = hipEventRecord(hh->ev_fork, hh->stream);
+            if (err == hipSuccess) err = hipStreamWaitEvent(hh->side_stream, hh->ev_fork, 0);
+            nl::StackArgs first = k->e;
+            first.list_count = k->snap;
+            if (err == hipSuccess) err = nl::launch_stack_sigma_coop(k->mode, first, kCoopGrid, hh->side_stream, &ignored);
+            if (err == hipSuccess) err = hipEventRecord(hh->ev_join, hh->side_stream);
+            k->err = err;
+        };
+        int fast_grid = 0;
+        if (a.n_frames <= 128)
+            NL_HIP(nl::launch_stack_sigma_fast(a, f, &fast_grid, h->stream, &h->last_kernel, h->ev_dom1,
+                                               mode == NL_ST_WINSOR_SIGMA, after, &fork));
+        else   // 129..512 frames: 2 or 4 lanes per pixel
+            NL_HIP(nl::launch_stack_sigma_ml(a, f, h->stream, &h->last_kernel, h->ev_dom1,
+                                             mode == NL_ST_WINSOR_SIGMA, after, &fork));
+        NL_HIP(fork.err);
         const char *exact_name = "";
-        if (nl::coop_supported(mode, weighted, a.n_frames)) {
-            NL_HIP(nl::launch_stack_sigma_coop(mode, e, kCoopGrid, h->stream, &exact_name));
+        if (coop) {
+            e.list_begin = snap;                          // the generic pass's additions
+            NL_HIP(nl::launch_stack_sigma_coop(mode, e, kCoopGrid / 4, h->stream, &exact_name));
+            NL_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         } else {
             int lanes = 0;
             size_t lds = 0;

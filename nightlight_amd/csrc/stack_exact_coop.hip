@@ -160,7 +160,9 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
     }
     long long c_lo = 0, c_hi = 0;
 
-    for (int64_t item = blockIdx.x; item < limit; item += gridDim.x) {
+    int64_t first = 0;
+    if (p.list && p.list_begin) first = min((int64_t)*p.list_begin, limit);
+    for (int64_t item = first + blockIdx.x; item < limit; item += gridDim.x) {
         const int64_t pix = p.list ? (int64_t)p.list[item] : item;
         const float *fr = p.frames + pix;
         lds_fence();

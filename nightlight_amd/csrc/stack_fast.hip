@@ -459,7 +459,8 @@ static const char *sigma_kernel_name()
 
 template <int NS, bool WINSOR>
 static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned tile_blocks,
-                        hipStream_t stream, const char **name, hipEvent_t dominant_done)
+                        hipStream_t stream, const char **name, hipEvent_t dominant_done,
+                        AfterDominant after, void *user)
 {
     FastArgs f = fargs;
     f.in_list = nullptr;
@@ -470,6 +471,7 @@ static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned t
         hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true, WINSOR>), dim3(tile_blocks), dim3(256), 0,
                            stream, args, f);
         if (dominant_done) (void)hipEventRecord(dominant_done, stream);
+        if (after) after(user);
         // generic pass over the pixels the zonal waves handed over (its length
         // is only known on the device: fixed grid, grid-stride loop)
         f.in_list = fargs.gen_list;
@@ -484,36 +486,37 @@ static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned t
         hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false, WINSOR>), dim3(tile_blocks), dim3(256), 0,
                            stream, args, f);
         if (dominant_done) (void)hipEventRecord(dominant_done, stream);
+        if (after) after(user);
     }
 }
 
 template <bool WINSOR>
 static void launch_sized(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name,
-                         hipEvent_t dominant_done)
+                         hipEvent_t dominant_done, AfterDominant after, void *user)
 {
     const unsigned blocks = (unsigned)((args.npix + 255) / 256);
     const int n = args.n_frames;
     // network sizes: the frame count rounded up to the next instantiated size;
     // unused positions count as missing samples
-    if (n <= 8)        launch_pair<8, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
-    else if (n <= 16)  launch_pair<16, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
-    else if (n <= 24)  launch_pair<24, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
-    else if (n <= 32)  launch_pair<32, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
-    else if (n <= 48)  launch_pair<48, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
-    else if (n <= 64)  launch_pair<64, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
-    else if (n <= 80)  launch_pair<80, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
-    else if (n <= 96)  launch_pair<96, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
-    else if (n <= 112) launch_pair<112, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
-    else               launch_pair<128, WINSOR>(args, fargs, blocks, stream, name, dominant_done);
+    if (n <= 8)        launch_pair<8, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else if (n <= 16)  launch_pair<16, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else if (n <= 24)  launch_pair<24, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else if (n <= 32)  launch_pair<32, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else if (n <= 48)  launch_pair<48, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else if (n <= 64)  launch_pair<64, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else if (n <= 80)  launch_pair<80, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else if (n <= 96)  launch_pair<96, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else if (n <= 112) launch_pair<112, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else               launch_pair<128, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
 }
 
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, int *blocks_used,
                                    hipStream_t stream, const char **name, hipEvent_t dominant_done,
-                                   bool winsor)
+                                   bool winsor, AfterDominant after, void *user)
 {
     *blocks_used = 0;
-    if (winsor) launch_sized<true>(args, fargs, stream, name, dominant_done);
-    else        launch_sized<false>(args, fargs, stream, name, dominant_done);
+    if (winsor) launch_sized<true>(args, fargs, stream, name, dominant_done, after, user);
+    else        launch_sized<false>(args, fargs, stream, name, dominant_done, after, user);
     return hipGetLastError();
 }
 

@@ -560,7 +560,7 @@ int fast_ml_supported(int mode, bool weighted, int n_frames, int64_t npix)
 
 template <int LPP, bool WINSOR>
 static void launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
-                      hipEvent_t dominant_done)
+                      hipEvent_t dominant_done, AfterDominant after, void *user)
 {
     const unsigned per_wg = 256 / LPP;
     const unsigned tile_blocks = (unsigned)((args.npix + per_wg - 1) / per_wg);
@@ -570,6 +570,7 @@ static void launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t 
     f.in_capacity = 0;
     hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, true, WINSOR>), dim3(tile_blocks), dim3(256), 0, stream, args, f);
     if (dominant_done) (void)hipEventRecord(dominant_done, stream);
+    if (after) after(user);
     f.in_list = fargs.gen_list;
     f.in_count = fargs.gen_count;
     f.in_capacity = fargs.gen_capacity;
@@ -579,16 +580,17 @@ static void launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t 
 
 // kernel names as rocprofv3 prints them (template arguments: LPP, ZONAL, WINSOR)
 hipError_t launch_stack_sigma_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
-                                 const char **name, hipEvent_t dominant_done, bool winsor)
+                                 const char **name, hipEvent_t dominant_done, bool winsor,
+                                 AfterDominant after, void *user)
 {
     if (args.n_frames <= 256) {
         *name = winsor ? "stack_sigma_ml_kernel<2, true, true>" : "stack_sigma_ml_kernel<2, true, false>";
-        if (winsor) launch_ml<2, true>(args, fargs, stream, dominant_done);
-        else        launch_ml<2, false>(args, fargs, stream, dominant_done);
+        if (winsor) launch_ml<2, true>(args, fargs, stream, dominant_done, after, user);
+        else        launch_ml<2, false>(args, fargs, stream, dominant_done, after, user);
     } else {
         *name = winsor ? "stack_sigma_ml_kernel<4, true, true>" : "stack_sigma_ml_kernel<4, true, false>";
-        if (winsor) launch_ml<4, true>(args, fargs, stream, dominant_done);
-        else        launch_ml<4, false>(args, fargs, stream, dominant_done);
+        if (winsor) launch_ml<4, true>(args, fargs, stream, dominant_done, after, user);
+        else        launch_ml<4, false>(args, fargs, stream, dominant_done, after, user);
     }
     return hipGetLastError();
 }

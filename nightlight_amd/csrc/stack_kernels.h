@@ -28,6 +28,7 @@ struct StackArgs {
     const unsigned *list;         // optional: pixel indices to process instead of 0..npix-1
     const unsigned *list_count;   // device-side length of `list`
     unsigned list_capacity;
+    const unsigned *list_begin;   // device-side first item to process (nullptr: 0); wave-per-pixel replay only
 };
 
 // fallback list written by the fast kernels, consumed by the exact kernel
@@ -56,14 +57,18 @@ hipError_t launch_reduce_counters(const unsigned long long *partial, int n_block
 int fast_supported(int mode, bool weighted, int n_frames);
 hipError_t launch_stack_median_fast(const StackArgs &args, hipStream_t stream, const char **name);
 // dominant_done (optional) is recorded right after the first, dominant kernel
+// after_dominant(user) is called between the launch of the dominant (zonal) kernel and
+// the generic pass, so the caller can start work that only depends on the former
+typedef void (*AfterDominant)(void *user);
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, int *blocks_used,
                                    hipStream_t stream, const char **name, hipEvent_t dominant_done,
-                                   bool winsor);
+                                   bool winsor, AfterDominant after_dominant, void *user);
 
 // ---- stack_fast_ml.hip (129..512 frames, 2 or 4 lanes per pixel) ----
 int fast_ml_supported(int mode, bool weighted, int n_frames, int64_t npix);
 hipError_t launch_stack_sigma_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
-                                 const char **name, hipEvent_t dominant_done, bool winsor);
+                                 const char **name, hipEvent_t dominant_done, bool winsor,
+                                 AfterDominant after_dominant, void *user);
 
 // ---- stack_exact_coop.hip (bit-exact sigma replay, one wave per pixel) ----
 int coop_supported(int mode, bool weighted, int n_frames);

@@ -18,6 +18,8 @@
 //
 // StackSigma: internal/ops/stack/stack.go:372-436.  HBM traffic: every sample is
 // read once; a wave instruction covers 64/LPP consecutive pixels of LPP frames.
+#include <string>
+
 #include "fast_common.hpp"
 
 namespace nl {
@@ -156,16 +158,21 @@ __device__ __forceinline__ float pick_rank(const float (&v)[NS], int g, int role
 }
 
 // ZONAL / generic exactly as in stack_fast.hip; LPP lanes per pixel.
+// WIDE (zonal only): for frame counts well below LPP*128.  The unused positions sort
+// to the top as +Inf, so the last lanes hold nothing but padding and the high
+// zone has to reach down to the last real samples: it covers a whole lane
+// except its 8 lowest ranks, the last lane holding data (LAST) is found at run
+// time from the frame count, and the median is looked up over whole lanes.
+// Valid while more than LAST*128 + 8 samples are present.
 // (zonal sigma: the allocator lands one register above the 168 that let 3 waves share a SIMD)
-template <int LPP, bool ZONAL, bool WINSOR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZONAL && !WINSOR ? 3 : 1, 8)))
+template <int LPP, bool ZONAL, bool WINSOR, bool WIDE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZONAL && !WINSOR && !WIDE ? 3 : 1, 8)))
 void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
 {
     constexpr int NS = kMlNS, NT = NS * LPP;
     constexpr int ZL = kZone;                        // low zone : ranks [0, ZL)           (role 0)
-    constexpr int ZHS = kZone + kPadMax;             // high zone: ranks [NT-ZHS, NT)      (last role)
-    constexpr int ZH = ZONAL ? NT - ZHS : NT;
-    constexpr int LAST = LPP - 1;
+    static_assert(!WIDE || ZONAL, "WIDE is a zonal variant");
+    constexpr int ZHS = WIDE ? NS - kZone : kZone + kPadMax;   // high zone: the ZHS highest ranks of lane LAST
 
     int c_lo_total = 0, c_hi_total = 0;
     const bool listed = !ZONAL && q.in_list != nullptr;
@@ -178,6 +185,10 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
     for (int64_t wg_item = (int64_t)blockIdx.x * items_per_wg; wg_item < limit; wg_item += sweep) {
         int N = p.n_frames;
         asm volatile("" : "+s"(N));
+        // last lane that holds samples, ranks in use, first rank of the high zone
+        const int LAST = WIDE ? (N - 1) / NS : LPP - 1;
+        const int NTE = (LAST + 1) * NS;
+        const int ZH = ZONAL ? NTE - ZHS : NT;
         const int64_t item = wg_item + threadIdx.x / LPP;
         const bool on = item < limit;
         int64_t pix = item;
@@ -242,12 +253,12 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
         constexpr int KEEP = 16;
         static_assert(kZone + kPadMax <= KEEP, "zones must lie inside the sorted ends");
         cross_stage<NS, kSwap1, true>(v, (role & 1) == 0);
-        if constexpr (ZONAL && LPP == 2) half_clean_ends<NS, NS / 2, KEEP>(v);
+        if constexpr (ZONAL && !WIDE && LPP == 2) half_clean_ends<NS, NS / 2, KEEP>(v);
         else                             half_clean<NS, NS / 2>(v);
         if constexpr (LPP == 4) {
             cross_stage<NS, kMirror, true>(v, role < 2);
             cross_stage<NS, kSwap1, false>(v, (role & 1) == 0);
-            if constexpr (ZONAL) half_clean_ends<NS, NS / 2, KEEP>(v);
+            if constexpr (ZONAL && !WIDE) half_clean_ends<NS, NS / 2, KEEP>(v);
             else                 half_clean<NS, NS / 2>(v);
         }
         const int n = quad_sum<LPP>(NS - nan_cnt);
@@ -266,7 +277,7 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
         // median windows of the zonal passes: a in [0,ZL), b in (ZH,NT] => the two
         // middle ranks lie in [NT/2 - ZHS/2 - 1, NT/2 + ZL/2], i.e. at the top of
         // lane LPP/2-1 and at the bottom of lane LPP/2
-        constexpr int TOPW = ZONAL ? ZHS / 2 + 2 : NS, BOTW = ZONAL ? ZL / 2 + 2 : NS;
+        constexpr int TOPW = (ZONAL && !WIDE) ? ZHS / 2 + 2 : NS, BOTW = (ZONAL && !WIDE) ? ZL / 2 + 2 : NS;
         constexpr int MIDR = LPP / 2 - 1;
         const float c = pick_rank<LPP, NS, TOPW, BOTW>(v, a + ((b - a) >> 1), role, MIDR);
 
@@ -296,6 +307,10 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
             float dl = (m0 + m1) + (m2 + m3), ql = (r0 + r1) + (r2 + r3);
             dl += (role == 0 ? 0.0f : d0) + (role == LAST ? 0.0f : d1);
             ql += (role == 0 ? 0.0f : q0) + (role == LAST ? 0.0f : q1);
+            if constexpr (WIDE) {                  // lanes above LAST hold only padding
+                dl = role > LAST ? 0.0f : dl;
+                ql = role > LAST ? 0.0f : ql;
+            }
             d_mid = quad_sum<LPP>(dl);
             q_mid = quad_sum<LPP>(ql);
         }
@@ -308,6 +323,10 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
         }
 
         while (__any(active)) {
+            // WIDE: re-materialised per pass, otherwise the 120 differences v[k] - c of the
+            // wide zone are hoisted out of the loop and cost 120 registers
+            float cz = c;
+            if constexpr (WIDE) asm volatile("" : "+v"(cz));
             const int cnt = b - a;
             const float fcnt = (float)cnt;
             float dz = 0.0f, qz = 0.0f;
@@ -315,14 +334,14 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
                 float dz0 = 0, qz0 = 0, dz1 = 0, qz1 = 0;
                 static_range<0, ZL>([&](auto K) NL_INL {
                     constexpr int k = decltype(K)::value;
-                    const float e = (k >= a) ? v[k] - c : 0.0f;
+                    const float e = (k >= a) ? v[k] - cz : 0.0f;
                     dz0 += e;
                     qz0 = __builtin_fmaf(e, e, qz0);
                 });
                 const int b_local = b - LAST * NS;
                 static_range<NS - ZHS, NS>([&](auto K) NL_INL {
                     constexpr int k = decltype(K)::value;
-                    const float e = (k < b_local) ? v[k] - c : 0.0f;
+                    const float e = (k < b_local) ? v[k] - cz : 0.0f;
                     dz1 += e;
                     qz1 = __builtin_fmaf(e, e, qz1);
                 });
@@ -337,8 +356,8 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
                     const bool i1 = (unsigned)(k + 1 - a1) < (unsigned)cnt;
                     const bool i2 = (unsigned)(k + 2 - a1) < (unsigned)cnt;
                     const bool i3 = (unsigned)(k + 3 - a1) < (unsigned)cnt;
-                    const float e0 = i0 ? v[k + 0] - c : 0.0f, e1 = i1 ? v[k + 1] - c : 0.0f;
-                    const float e2 = i2 ? v[k + 2] - c : 0.0f, e3 = i3 ? v[k + 3] - c : 0.0f;
+                    const float e0 = i0 ? v[k + 0] - cz : 0.0f, e1 = i1 ? v[k + 1] - cz : 0.0f;
+                    const float e2 = i2 ? v[k + 2] - cz : 0.0f, e3 = i3 ? v[k + 3] - cz : 0.0f;
                     d0 += e0; d1 += e1; d2 += e2; d3 += e3;
                     q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
                     q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
@@ -386,31 +405,33 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
                 const float inv_cnt = 1.0f / fcnt;
                 bool inner = active && !bail;
                 // ranks below a / from b on are excluded: only lane 0 / the last lane see them
-                const int a_loc = role == 0 ? a : 0;
-                const int b_loc = role == LAST ? b - LAST * NS : NS;
+                const int a_loc = role == 0 ? a : (role > LAST ? NS : 0);
+                const int b_loc = role == LAST ? b - LAST * NS : (role > LAST ? 0 : NS);
                 while (__any(inner)) {
+                    // (re-materialised per round: otherwise one lane mask per position is kept in SGPRs)
+                    const int al = opaque(a_loc), bl = opaque(b_loc);
                     wi.next_clamp(median, xmin, xmax);
                     auto clamped_variance = [&](const float Lt, const float Ht, float &wvar, float &werr) NL_INL {
                         float d0 = 0, d1 = 0, d2 = 0, d3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
                         if constexpr (ZONAL) {
                             static_range<0, ZL>([&](auto K) NL_INL {
                                 constexpr int k = decltype(K)::value;
-                                const float e = (k >= a_loc) ? __builtin_amdgcn_fmed3f(v[k], Lt, Ht) - c : 0.0f;
+                                const float e = (k >= al) ? __builtin_amdgcn_fmed3f(v[k], Lt, Ht) - cz : 0.0f;
                                 d0 += e; q0 = __builtin_fmaf(e, e, q0);
                             });
                             static_chunks<0, (NS - ZHS - ZL) / 4, 4>([&](auto K) NL_INL {
                                 constexpr int k = ZL + 4 * decltype(K)::value;
-                                const float e0 = __builtin_amdgcn_fmed3f(v[k], Lt, Ht) - c;
-                                const float e1 = __builtin_amdgcn_fmed3f(v[k + 1], Lt, Ht) - c;
-                                const float e2 = __builtin_amdgcn_fmed3f(v[k + 2], Lt, Ht) - c;
-                                const float e3 = __builtin_amdgcn_fmed3f(v[k + 3], Lt, Ht) - c;
+                                const float e0 = __builtin_amdgcn_fmed3f(v[k], Lt, Ht) - cz;
+                                const float e1 = __builtin_amdgcn_fmed3f(v[k + 1], Lt, Ht) - cz;
+                                const float e2 = __builtin_amdgcn_fmed3f(v[k + 2], Lt, Ht) - cz;
+                                const float e3 = __builtin_amdgcn_fmed3f(v[k + 3], Lt, Ht) - cz;
                                 d0 += e0; d1 += e1; d2 += e2; d3 += e3;
                                 q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
                                 q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
                             });
                             static_range<NS - ZHS, NS>([&](auto K) NL_INL {
                                 constexpr int k = decltype(K)::value;
-                                const float e = (k < b_loc) ? __builtin_amdgcn_fmed3f(v[k], Lt, Ht) - c : 0.0f;
+                                const float e = (k < bl) ? __builtin_amdgcn_fmed3f(v[k], Lt, Ht) - cz : 0.0f;
                                 d1 += e; q1 = __builtin_fmaf(e, e, q1);
                             });
                         } else {
@@ -421,10 +442,10 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
                                 const bool i1 = (unsigned)(k + 1 - a4) < (unsigned)cnt;
                                 const bool i2 = (unsigned)(k + 2 - a4) < (unsigned)cnt;
                                 const bool i3 = (unsigned)(k + 3 - a4) < (unsigned)cnt;
-                                const float e0 = i0 ? __builtin_amdgcn_fmed3f(v[k + 0], Lt, Ht) - c : 0.0f;
-                                const float e1 = i1 ? __builtin_amdgcn_fmed3f(v[k + 1], Lt, Ht) - c : 0.0f;
-                                const float e2 = i2 ? __builtin_amdgcn_fmed3f(v[k + 2], Lt, Ht) - c : 0.0f;
-                                const float e3 = i3 ? __builtin_amdgcn_fmed3f(v[k + 3], Lt, Ht) - c : 0.0f;
+                                const float e0 = i0 ? __builtin_amdgcn_fmed3f(v[k + 0], Lt, Ht) - cz : 0.0f;
+                                const float e1 = i1 ? __builtin_amdgcn_fmed3f(v[k + 1], Lt, Ht) - cz : 0.0f;
+                                const float e2 = i2 ? __builtin_amdgcn_fmed3f(v[k + 2], Lt, Ht) - cz : 0.0f;
+                                const float e3 = i3 ? __builtin_amdgcn_fmed3f(v[k + 3], Lt, Ht) - cz : 0.0f;
                                 d0 += e0; d1 += e1; d2 += e2; d3 += e3;
                                 q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
                                 q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
@@ -469,7 +490,7 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
                 c1 = quad_sum<LPP>(role == 0 ? c1 : 0); c2 = quad_sum<LPP>(role == 0 ? c2 : 0);
                 d1 = quad_sum<LPP>(role == LAST ? d1 : 0); d2 = quad_sum<LPP>(role == LAST ? d2 : 0);
                 c1 = max(c1 - a, 0); c2 = max(c2 - a, 0);
-                d1 = max(d1 - (NT - b), 0); d2 = max(d2 - (NT - b), 0);
+                d1 = max(d1 - (NTE - b), 0); d2 = max(d2 - (NTE - b), 0);
                 if (active && ((a + c2 >= ZL) || (b - d2 <= ZH))) {
                     to_generic = true;
                     active = false;
@@ -558,7 +579,7 @@ int fast_ml_supported(int mode, bool weighted, int n_frames, int64_t npix)
             npix < ((int64_t)1 << 27)) ? 1 : 0;
 }
 
-template <int LPP, bool WINSOR>
+template <int LPP, bool WINSOR, bool WIDE>
 static void launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
                       hipEvent_t dominant_done, AfterDominant after, void *user)
 {
@@ -568,30 +589,49 @@ static void launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t 
     f.in_list = nullptr;
     f.in_count = nullptr;
     f.in_capacity = 0;
-    hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, true, WINSOR>), dim3(tile_blocks), dim3(256), 0, stream, args, f);
+    hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, true, WINSOR, WIDE>), dim3(tile_blocks), dim3(256), 0, stream,
+                       args, f);
     if (dominant_done) (void)hipEventRecord(dominant_done, stream);
     if (after) after(user);
     f.in_list = fargs.gen_list;
     f.in_count = fargs.gen_count;
     f.in_capacity = fargs.gen_capacity;
     const unsigned gblocks = tile_blocks < kGenericGrid ? tile_blocks : kGenericGrid;
-    hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, false, WINSOR>), dim3(gblocks), dim3(256), 0, stream, args, f);
+    hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, false, WINSOR, false>), dim3(gblocks), dim3(256), 0, stream,
+                       args, f);
 }
 
-// kernel names as rocprofv3 prints them (template arguments: LPP, ZONAL, WINSOR)
+template <int LPP>
+static void launch_ml_variant(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name,
+                              hipEvent_t dominant_done, bool winsor, AfterDominant after, void *user)
+{
+    // tight zones when (almost) every position is used, otherwise the wide variant while the
+    // last lane with samples holds more than 8 of them; in the few remaining cases the tight
+    // variant hands every pixel to the generic pass
+    const int n = args.n_frames, nt = LPP * kMlNS;
+    const bool wide = n < nt - 8 && n > ((n - 1) / kMlNS) * kMlNS + 8;
+    static const std::string names[4] = {
+        "stack_sigma_ml_kernel<" + std::to_string(LPP) + ", true, false, false>",
+        "stack_sigma_ml_kernel<" + std::to_string(LPP) + ", true, false, true>",
+        "stack_sigma_ml_kernel<" + std::to_string(LPP) + ", true, true, false>",
+        "stack_sigma_ml_kernel<" + std::to_string(LPP) + ", true, true, true>"};
+    *name = names[(winsor ? 2 : 0) + (wide ? 1 : 0)].c_str();
+    if (winsor) {
+        if (wide) launch_ml<LPP, true, true>(args, fargs, stream, dominant_done, after, user);
+        else      launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user);
+    } else {
+        if (wide) launch_ml<LPP, false, true>(args, fargs, stream, dominant_done, after, user);
+        else      launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user);
+    }
+}
+
+// kernel names as rocprofv3 prints them (template arguments: LPP, ZONAL, WINSOR, WIDE)
 hipError_t launch_stack_sigma_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
                                  const char **name, hipEvent_t dominant_done, bool winsor,
                                  AfterDominant after, void *user)
 {
-    if (args.n_frames <= 256) {
-        *name = winsor ? "stack_sigma_ml_kernel<2, true, true>" : "stack_sigma_ml_kernel<2, true, false>";
-        if (winsor) launch_ml<2, true>(args, fargs, stream, dominant_done, after, user);
-        else        launch_ml<2, false>(args, fargs, stream, dominant_done, after, user);
-    } else {
-        *name = winsor ? "stack_sigma_ml_kernel<4, true, true>" : "stack_sigma_ml_kernel<4, true, false>";
-        if (winsor) launch_ml<4, true>(args, fargs, stream, dominant_done, after, user);
-        else        launch_ml<4, false>(args, fargs, stream, dominant_done, after, user);
-    }
+    if (args.n_frames <= 2 * kMlNS) launch_ml_variant<2>(args, fargs, stream, name, dominant_done, winsor, after, user);
+    else                            launch_ml_variant<4>(args, fargs, stream, name, dominant_done, winsor, after, user);
     return hipGetLastError();
 }
 

@@ -28,9 +28,10 @@ namespace nl {
 template <int S>
 struct Col {
     float *p;
+    bool live;      // lanes beyond LANES (narrow tiles) alias lane 0's column: they may read it, never write it
     __device__ __forceinline__ float get(int i) const { return p[i * S]; }
-    __device__ __forceinline__ void set(int i, float v) const { p[i * S] = v; }
-    __device__ __forceinline__ Col<S> shifted(int k) const { return Col<S>{p + k * S}; }
+    __device__ __forceinline__ void set(int i, float v) const { if (live) p[i * S] = v; }
+    __device__ __forceinline__ Col<S> shifted(int k) const { return Col<S>{p + k * S, live}; }
 };
 
 // qsort.go:94-126, k is 1-based
@@ -224,8 +225,8 @@ __global__ __launch_bounds__(64) void stack_exact_kernel(StackArgs p)
     const int lane = threadIdx.x;
     const bool lane_on = lane < LANES;
     const int n_alloc = (MODE == NL_ST_LINEAR_FIT) ? p.n_pad : p.n_frames;
-    Col<LANES> a{lds + (lane_on ? lane : 0)};
-    Col<LANES> b{lds + (size_t)n_alloc * LANES + (lane_on ? lane : 0)};   // weights / abs-dev column
+    Col<LANES> a{lds + (lane_on ? lane : 0), lane_on};
+    Col<LANES> b{lds + (size_t)n_alloc * LANES + (lane_on ? lane : 0), lane_on};   // weights / abs-dev column
 
     int c_lo = 0, c_hi = 0;
 

@@ -376,3 +376,31 @@ def test_larger_stack_sigma_and_goal_seek(nl, oracle):
             assert (passes, cl, ch) == (op, ocl, och)
             assert (np.float32(sl), np.float32(sh)) == (osl, osh)
             assert (same_values if exact else close_values)(out, ores)
+
+
+@pytest.mark.parametrize("mode", [0, 2, 3, 5])
+@pytest.mark.parametrize("n", [520, 700])
+def test_more_than_512_frames_fall_back_to_the_exact_kernels(nl, oracle, mode, n):
+    # beyond the register-resident kernels (N > 512; N > 128 for median / linear fit) the
+    # default dispatch is the LDS exact kernel: bit-exact
+    width, height = 40, 3
+    frames = make_frames(n, width, height, seed=1000 + n, nan_frac=0.01)
+    got, gc, want, wc = run_both(nl, oracle, mode, frames, width, height, None, 2.75, 2.75, exact=False)
+    assert same_values(got, want), "%s n=%d: %s" % (MODES[mode], n, describe_mismatch(got, want))
+    if mode >= 2:
+        assert gc == wc
+
+
+def test_goal_seek_winsorized_512_frames_tile(nl, oracle):
+    # configuration C3 in miniature: 512 frames, winsorized sigma clip, bisection on the clip
+    # percentages (stackfindsigma.go:48-98) -- the multi-lane kernel keeps the counters exact,
+    # so the search takes the oracle's path
+    width, height, n = 64, 6, 512
+    frames = make_frames(n, width, height, seed=77, nan_frac=0.002)
+    op, ores, ocl, och, osl, osh = oracle.find_sigmas_bisect(3, frames, 0.5, 0.5, num_cpu=8)
+    with nl.StackHandle(n, width, height) as st:
+        st.upload_frames(frames)
+        out, cl, ch, sl, sh, passes = st.find_sigmas(3, 0.5, 0.5)
+    assert (passes, cl, ch) == (op, ocl, och)
+    assert (np.float32(sl), np.float32(sh)) == (osl, osh)
+    assert close_values(out, ores)

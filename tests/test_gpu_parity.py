@@ -404,3 +404,16 @@ def test_goal_seek_winsorized_512_frames_tile(nl, oracle):
     assert (passes, cl, ch) == (op, ocl, och)
     assert (np.float32(sl), np.float32(sh)) == (osl, osh)
     assert close_values(out, ores)
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("n", [200, 400, 600])
+def test_large_stacks_weighted_and_mad_on_the_exact_kernel(nl, oracle, mode, n):
+    # two LDS columns (values + weights / deviations): narrower tiles from 400 frames on
+    width, height = 48, 3
+    frames = make_frames(n, width, height, seed=2000 + n, nan_frac=0.01)
+    weights = None if mode == 4 else np.random.default_rng(n).uniform(0.2, 1.0, n).astype(np.float32)
+    got, gc, want, wc = run_both(nl, oracle, mode, frames, width, height, weights, 2.5, 3.0, exact=False)
+    assert same_values(got, want), "%s n=%d: %s" % (MODES[mode], n, describe_mismatch(got, want))
+    if mode >= 2:
+        assert gc == wc

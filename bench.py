@@ -45,6 +45,16 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(st, args, rows):
     """Times the oracle (oracle/nl_oracle.c, a C restatement of the Go reference:
     same batching rule, one worker per host core) on the first `rows` rows."""
@@ -63,8 +73,8 @@ def cpu_baseline(st, args, rows):
     return {"value": round(rows * w / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores,
             "kind": "port",
             "sample": "first %d rows x %d px x %d frames of the same synthetic stack, %s, "
-                      "C restatement of the Go reference (no Go toolchain), %.1f s"
-                      % (rows, w, n, MODE_NAMES[args.mode], dt)}, res, (cl, ch)
+                      "C restatement of the Go reference (no Go toolchain), %.1f s on %d threads of %s"
+                      % (rows, w, n, MODE_NAMES[args.mode], dt, cores, cpu_model())}, res, (cl, ch)
 
 
 def measured_traffic(kernel, args):

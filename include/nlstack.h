@@ -235,6 +235,18 @@ int nl_host_op_stack_apply_json(const char *json, int n_frames, int width, int h
                                 char *log_buf, int log_cap, char *err_buf, int err_cap);
 /* Unmarshal with defaults (stack.go:92-99), marshal back. */
 const char *nl_host_op_stack_roundtrip_json(const char *json);
+/* OpStackBatches (internal/ops/stack/stackbatches.go:46-217): partition the inputs
+ * into batches that fit stack_memory_mb (Context.StackMemoryMB, operator.go:41),
+ * stack every batch with the per-batch "stack" operator given as JSON, combine
+ * the batch results with StackIncremental / StackIncrementalFinalize weighted by
+ * the batch frame counts (stack.go:924-944).  Same log lines and error strings;
+ * the batch shuffle uses a fixed-seed generator instead of Go's math/rand. */
+int nl_host_op_stack_batches_apply_json(const char *per_batch_json, int n_frames, int width,
+                                        int height, const float *const *frames,
+                                        const float *exposure, int device, int max_threads,
+                                        int memory_mb, int stack_memory_mb, float *out,
+                                        float *exposure_out, char *log_buf, int log_cap,
+                                        char *err_buf, int err_cap);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,7 @@ EXPORTS = [
     "nl_stack_upload_frame_fits", "nl_stack_upload_frame_projected", "nl_stack_frame_affine",
     "nl_stack_download_result_fits", "nl_fits_decode", "nl_project_bilinear",
     "nl_host_op_stack_apply_json", "nl_host_op_stack_roundtrip_json",
+    "nl_host_op_stack_batches_apply_json",
 ]
 
 
@@ -128,6 +129,9 @@ def load():
     L.nl_host_op_stack_apply_json.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int,
                                               C.POINTER(_f32p), _f32p, _f32p, C.c_int, C.c_int,
                                               _f32p, _f32p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    L.nl_host_op_stack_batches_apply_json.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_f32p),
+                                                      _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p,
+                                                      C.c_char_p, C.c_int, C.c_char_p, C.c_int]
     L.nl_host_op_stack_roundtrip_json.argtypes = [C.c_char_p]
     L.nl_host_op_stack_roundtrip_json.restype = C.c_char_p
     _lib = L

@@ -296,6 +296,150 @@ Result OpStack::Apply(const std::vector<ImagePtr> &f, Context *c)
 
 }  // namespace nightlight
 
+// ---- OpStackBatches (internal/ops/stack/stackbatches.go) ----------------------------
+namespace nightlight {
+
+std::shared_ptr<OpStackBatches> NewOpStackBatches(std::shared_ptr<OpStack> perBatch)
+{
+    auto op = std::make_shared<OpStackBatches>();
+    op->Type = "stackBatches";
+    op->PerBatch = std::move(perBatch);
+    return op;
+}
+
+std::vector<Promise> OpStackBatches::MakePromises(const std::vector<Promise> &ins, Context *c, std::string *err)
+{
+    if (ins.empty()) { *err = "No frames to batch process"; return {}; }          // :47-49
+    std::vector<Promise> copy = ins;
+    return {[this, copy, c]() { return Apply(copy, c); }};
+}
+
+// stack.go:924-937: the first light seeds the stack (copy scaled by weight), later ones add
+ImagePtr StackIncremental(ImagePtr stack, const ImagePtr &light, float weight)
+{
+    if (!stack) {
+        stack = std::make_shared<Image>(*light);                    // fits.NewImageFromImage
+        for (size_t i = 0; i < light->Data.size(); i++) stack->Data[i] = light->Data[i] * weight;
+    } else {
+        stack->Exposure += light->Exposure;
+        for (size_t i = 0; i < light->Data.size(); i++) {
+            const float t = light->Data[i] * weight;                // product rounded, then added (no FMA)
+            stack->Data[i] += t;
+        }
+    }
+    return stack;
+}
+
+// stack.go:940-944 (the extended statistics are recomputed lazily by whoever needs them)
+void StackIncrementalFinalize(const ImagePtr &stack, float weightSum)
+{
+    const float factor = 1.0f / weightSum;
+    for (float &d : stack->Data) d = d * factor;
+}
+
+bool OpStackBatches::partition(const std::vector<Promise> &ins, Context *c, std::vector<Promise> *insPerm,
+                               int64_t *numBatches, int64_t *batchSize, int64_t *maxThreads, std::string *err)
+{
+    const int64_t numFrames = (int64_t)ins.size();
+    if (ins.empty()) { *err = "No input files to prepare batches"; return false; }            // :137
+    Result first = ins[0]();                                                                    // :130
+    if (!first.err.empty()) { *err = first.err; return false; }
+    if (!first.image) { *err = "No input files to prepare batches"; return false; }
+    char line[512];
+    snprintf(line, sizeof line, "\nEstimating memory needs for %lld images from %s:\n", (long long)numFrames,
+             first.image->FileName.c_str());
+    if (c->Log) *c->Log << line;
+    const int64_t width = first.image->Naxisn[0], height = first.image->Naxisn[1];
+    const int64_t pixels = width * height;
+    const float mPixels = (float)width * (float)height * 1e-6f;
+    const int64_t bytes = pixels * 4;
+    const int64_t mib = bytes / 1024 / 1024;
+    snprintf(line, sizeof line,
+             "%lld images of %lldx%lld pixels (%.1f MPixels), which each take %lld MiB in-memory as floating point.\n",
+             (long long)numFrames, (long long)width, (long long)height, mPixels, (long long)mib);
+    if (c->Log) *c->Log << line;
+
+    const int64_t availableFrames = ((int64_t)c->StackMemoryMB * 1024 * 1024) / bytes;         // :148
+    int64_t mt = c->MaxThreads > 0 ? c->MaxThreads : 1;                                         // runtime.GOMAXPROCS(0)
+    snprintf(line, sizeof line,
+             "CPU has %lld threads. Physical memory is %d MiB, -op.Memory is %d MiB, this fits %lld frames.\n",
+             (long long)mt, c->MemoryMB, c->StackMemoryMB, (long long)availableFrames);
+    if (c->Log) *c->Log << line;
+
+    int64_t bs = 0, nb = 0;
+    for (; mt >= 1; mt--) {                                                                     // :154-180
+        bs = availableFrames - mt;             // lights + one temp frame per thread (no dark / flat here)
+        if (bs < 2) continue;
+        nb = (numFrames + bs - 1) / bs;
+        if (nb > 1) bs -= 2;                   // reference frame from batch 0, and the stack of stacks
+        if (bs < 2) continue;
+        if (bs < mt) continue;
+        break;
+    }
+    if (mt < 1 || bs < 2) {
+        *err = "Cannot find a stacking execution path within the given memory constraints.";
+        return false;
+    }
+    for (; (bs - 1) * nb >= numFrames; bs--) {}                                                 // :185-186
+    snprintf(line, sizeof line, "Using %lld random batches of size %lld with %lld images in parallel.\n",
+             (long long)nb, (long long)bs, (long long)mt);
+    if (c->Log) *c->Log << line;
+
+    *insPerm = ins;
+    if (nb > 1) {                                                                               // :190-214
+        if (c->Log) *c->Log << "Randomizing input files into batches...\n";
+        uint64_t state = 0x9E3779B97F4A7C15ull;
+        for (size_t i = insPerm->size(); i > 1; i--) {
+            state = state * 6364136223846793005ull + 1442695040888963407ull;
+            const size_t j = (size_t)((state >> 33) % i);
+            std::swap((*insPerm)[i - 1], (*insPerm)[j]);
+        }
+    }
+    *numBatches = nb; *batchSize = bs; *maxThreads = mt;
+    return true;
+}
+
+Result OpStackBatches::Apply(const std::vector<Promise> &ins, Context *c)
+{
+    std::vector<Promise> insPerm;
+    int64_t numBatches = 0, batchSize = 0, maxThreads = 0;
+    std::string err;
+    if (!partition(ins, c, &insPerm, &numBatches, &batchSize, &maxThreads, &err)) return {nullptr, err};
+    c->MaxThreads = (int)maxThreads;                                                            // :62
+    c->StatsTotal = (int)insPerm.size();
+    c->StatsProcessed = 0;
+
+    ImagePtr stack;
+    int64_t stackFrames = 0;
+    for (int64_t b = 0; b < numBatches; b++) {                                                  // :69
+        const int64_t start = b * batchSize;
+        const int64_t end = std::min<int64_t>((b + 1) * batchSize, (int64_t)insPerm.size());
+        const int64_t batchFrames = end - start;
+        std::vector<Promise> insBatch(insPerm.begin() + start, insPerm.begin() + end);
+        char line[160];
+        snprintf(line, sizeof line, "\nStarting batch %lld of %lld with %zu frames...\n", (long long)(b + 1),
+                 (long long)numBatches, insBatch.size());
+        if (c->Log) *c->Log << line;
+        if (!PerBatch) return {nullptr, "Missing batch parameters"};                            // :82-84
+        std::vector<Promise> batchPromises = PerBatch->MakePromises(insBatch, c, &err);
+        if (!err.empty()) return {nullptr, err};
+        if (batchPromises.size() != 1) return {nullptr, "stacking returned more than one promise"};
+        Result batch = batchPromises[0]();                                                      // :92
+        if (!batch.err.empty()) return {nullptr, batch.err};
+        if (numBatches > 1) {                                                                   // :98-103
+            stack = StackIncremental(stack, batch.image, (float)batchFrames);
+            stackFrames += batchFrames;
+        } else {
+            stack = batch.image;
+        }
+    }
+    if (numBatches > 1) StackIncrementalFinalize(stack, (float)stackFrames);                    // :113-116
+    return {stack, ""};
+}
+
+}  // namespace nightlight
+
+
 // ---- plain-C entry used by the tests (and by other hosts that only have
 // host buffers): decode the operator from JSON exactly as OpSequence would
 // (operator.go:484-513: factory lookup by "type", then UnmarshalJSON), run it
@@ -359,4 +503,51 @@ extern "C" const char *nl_host_op_stack_roundtrip_json(const char *json)
     if (!op->UnmarshalJSON(json ? json : "{}", &err)) { out = "error: " + err; return out.c_str(); }
     out = op->MarshalJSON();
     return out.c_str();
+}
+
+
+// OpStackBatches with the given per-batch operator (JSON of type "stack") over frames
+// supplied as promises; stack_memory_mb steers the partition (operator.go:41).
+extern "C" int nl_host_op_stack_batches_apply_json(const char *per_batch_json, int n_frames, int width, int height,
+                                                   const float *const *frames, const float *exposure,
+                                                   int device, int max_threads, int memory_mb, int stack_memory_mb,
+                                                   float *out, float *exposure_out, char *log_buf, int log_cap,
+                                                   char *err_buf, int err_cap)
+{
+    using namespace nightlight;
+    auto put = [](char *dst, int cap, const std::string &s) {
+        if (dst && cap > 0) { snprintf(dst, (size_t)cap, "%s", s.c_str()); }
+    };
+    put(err_buf, err_cap, "");
+    put(log_buf, log_cap, "");
+    auto per = NewOpStackDefault();
+    std::string err;
+    if (!per->UnmarshalJSON(per_batch_json ? per_batch_json : "{}", &err)) { put(err_buf, err_cap, err); return 1; }
+    auto op = NewOpStackBatches(per);
+    std::ostringstream log;
+    Context ctx;
+    ctx.Log = &log;
+    ctx.MaxThreads = max_threads > 0 ? max_threads : 1;
+    ctx.MemoryMB = memory_mb;
+    ctx.StackMemoryMB = stack_memory_mb;
+    ctx.Device = device;
+    std::vector<Promise> ins;
+    for (int i = 0; i < n_frames; i++) {
+        ins.push_back([=]() -> Result {
+            std::vector<float> d(frames[i], frames[i] + (size_t)width * height);
+            ImagePtr img = NewImageFromNaxisn({width, height}, std::move(d));
+            img->ID = i;
+            img->FileName = "frame" + std::to_string(i) + ".fits";
+            img->Exposure = exposure ? exposure[i] : 0.0f;
+            return {img, ""};
+        });
+    }
+    std::vector<Promise> outs = op->MakePromises(ins, &ctx, &err);
+    if (!err.empty()) { put(err_buf, err_cap, err); put(log_buf, log_cap, log.str()); return 1; }
+    Result r = outs[0]();
+    put(log_buf, log_cap, log.str());
+    if (!r.err.empty() || !r.image) { put(err_buf, err_cap, r.err.empty() ? "no result" : r.err); return 1; }
+    if (out) memcpy(out, r.image->Data.data(), r.image->Data.size() * sizeof(float));
+    if (exposure_out) *exposure_out = r.image->Exposure;
+    return 0;
 }

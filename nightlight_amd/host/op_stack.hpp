@@ -34,6 +34,28 @@ std::shared_ptr<OpStack> NewOpStackDefault();                                   
 // stack.go:75 -- `init()` registers the factory for JSON decoding of type "stack"
 void RegisterOpStack();
 
+// internal/ops/stack/stackbatches.go:31-217 -- stacks the inputs in memory-sized batches with
+// the given per-batch stack operator and combines the batch results into a frame-count
+// weighted stack of stacks (StackIncremental / StackIncrementalFinalize, stack.go:924-944).
+struct OpStackBatches : Operator, OpBase {
+    std::shared_ptr<OpStack> PerBatch;    // json:"perBatch"
+
+    std::string GetType() const override { return Type; }
+    std::vector<Promise> MakePromises(const std::vector<Promise> &ins, Context *c,
+                                      std::string *err) override;      // stackbatches.go:46-54
+    Result Apply(const std::vector<Promise> &ins, Context *c);         // :56-119
+    // :121-217.  The reference shuffles the inputs with math/rand's global generator; this
+    // mirror uses a fixed-seed Fisher-Yates shuffle instead (the batch composition is a free
+    // choice of the algorithm, not part of its result contract).
+    bool partition(const std::vector<Promise> &ins, Context *c, std::vector<Promise> *insPerm,
+                   int64_t *numBatches, int64_t *batchSize, int64_t *maxThreads, std::string *err);
+};
+std::shared_ptr<OpStackBatches> NewOpStackBatches(std::shared_ptr<OpStack> perBatch);   // stackbatches.go:39-44
+
+// stack.go:924-944
+ImagePtr StackIncremental(ImagePtr stack, const ImagePtr &light, float weight);
+void StackIncrementalFinalize(const ImagePtr &stack, float weightSum);
+
 // getWeights, stack.go:231-270 (returns an empty vector for StWeightNone)
 std::vector<float> getWeights(const std::vector<ImagePtr> &f, int weighting, std::string *err);
 

@@ -61,7 +61,9 @@ using Promise = std::function<Result()>;
 struct Context {
     std::ostream *Log = nullptr;
     int MaxThreads = 1;
-    int StackMemoryMB = 0;
+    int MemoryMB = 0;                   // operator.go:40
+    int StackMemoryMB = 0;              // operator.go:41 (MemoryMB*7/10)
+    int StatsTotal = 0, StatsProcessed = 0;
     int Device = 0;                     // not in the reference: which GPU the HIP operator uses
 };
 

@@ -39,3 +39,25 @@ def op_stack_apply_json(text, frames, width, height, exposure=None, hfr=None, de
     if rc != 0:
         raise OperatorError(err.value.decode())
     return out, float(exp_out.value), log.value.decode()
+
+
+def op_stack_batches_apply_json(per_batch_json, frames, width, height, exposure=None, device=0,
+                                max_threads=4, memory_mb=0, stack_memory_mb=0):
+    """OpStackBatches (stackbatches.go:46-217) over host frames.
+    Returns (result, exposure_sum, log); raises OperatorError with the reference's message."""
+    lib = capi.load()
+    f32p = C.POINTER(C.c_float)
+    keep = [np.ascontiguousarray(f, np.float32).reshape(-1) for f in frames]
+    ptrs = (f32p * max(len(keep), 1))(*[k.ctypes.data_as(f32p) for k in keep])
+    out = np.zeros(width * height, np.float32)
+    exp_out = C.c_float(0)
+    log = C.create_string_buffer(16384)
+    err = C.create_string_buffer(1024)
+    e = None if exposure is None else np.ascontiguousarray(exposure, np.float32)
+    rc = lib.nl_host_op_stack_batches_apply_json(
+        per_batch_json.encode(), len(keep), int(width), int(height), ptrs,
+        None if e is None else capi.fptr(e), int(device), int(max_threads), int(memory_mb),
+        int(stack_memory_mb), capi.fptr(out), C.byref(exp_out), log, len(log), err, len(err))
+    if rc != 0:
+        raise OperatorError(err.value.decode() + ("\n" + log.value.decode() if log.value else ""))
+    return out, float(exp_out.value), log.value.decode()

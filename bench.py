@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=0,
                     help="rows of the stack timed on the CPU (0 = auto, about 10-30 s)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank path)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses device 0 (needs --backend gloo)")
     return ap.parse_args()
 
 
@@ -106,23 +110,28 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    device = 0 if args.share_device else local_rank
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=args.backend)
+    comm_device = "cuda" if args.backend == "nccl" else "cpu"
 
     n, w, rows = args.frames, args.width, args.height
     total_rows = rows * world
-    st = StackHandle(n, w, total_rows, row0=rank * rows, rows=rows, device=local_rank)
+    st = StackHandle(n, w, total_rows, row0=rank * rows, rows=rows, device=device)
     st.fill_synthetic()
-    counters = torch.zeros(2, dtype=torch.int64, device="cuda")
+    counters = torch.zeros(2, dtype=torch.int64, device=comm_device)
 
     def step():
         st.run_async(args.mode, args.kappa, args.kappa, 0.0)
         cl, ch = st.finish()
         if dist is not None:     # global clip totals, as the log line of stack.go:214-218 needs
-            counters[0], counters[1] = cl, ch
+            counters.copy_(torch.tensor([cl, ch], dtype=torch.int64))
             dist.all_reduce(counters)
         return cl, ch
 
@@ -144,7 +153,7 @@ def main():
     dt = time.perf_counter() - t0
 
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -188,7 +197,7 @@ def main():
             # parity in the same run: the same strip through the C ABI vs the oracle.
             # Clip counters must be equal; values within the north star's 1e-5
             # (bit-exact for every kernel but the register-resident sigma one).
-            with StackHandle(n, w, total_rows, row0=0, rows=cpu_rows, device=local_rank) as strip:
+            with StackHandle(n, w, total_rows, row0=0, rows=cpu_rows, device=device) as strip:
                 strip.fill_synthetic()
                 got, gl, gh = strip.run(args.mode, args.kappa, args.kappa, 0.0)
                 got = got[: cpu_rows * w]

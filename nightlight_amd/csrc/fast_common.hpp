@@ -235,17 +235,14 @@ __device__ __forceinline__ int gather_sorted(const float *frames, int64_t stride
     int nan_cnt = 0;
     if (__any(!(__builtin_fabsf(total) < __builtin_inff()))) {
         // NaN <=> (bits & 0x7fffffff) > 0x7f800000; counted with integer arithmetic
-        // (a compare would park a lane mask in SGPRs per element); the column is
-        // only read here
+        // (a compare would park a lane mask in SGPRs per element), then NaN -> +Inf in
+        // place (tied asm operand: the column keeps its registers across the branch)
         static_chunks<0, NS, 8>([&](auto K) NL_INL {
             constexpr int k = decltype(K)::value;
             nan_cnt = opaque(nan_cnt - ((0x7f800000 - (__float_as_int(v[k]) & 0x7fffffff)) >> 31));
+            asm volatile("v_min_f32 %0, %0, %1" : "+v"(v[k]) : "v"(__builtin_inff()));
         });
     }
-    static_chunks<0, NS, 16>([&](auto K) NL_INL {
-        constexpr int k = decltype(K)::value;
-        v[k] = nan_to_inf(v[k]);
-    });
     SORT::template apply<NS>(v);
     return NS - nan_cnt;
 }

@@ -240,12 +240,9 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
                 static_chunks<0, NS, 8>([&](auto K) NL_INL {
                     constexpr int k = decltype(K)::value;
                     nan_cnt = opaque(nan_cnt - ((0x7f800000 - (__float_as_int(v[k]) & 0x7fffffff)) >> 31));
+                    asm volatile("v_min_f32 %0, %0, %1" : "+v"(v[k]) : "v"(__builtin_inff()));   // NaN -> +Inf in place
                 });
             }
-            static_chunks<0, NS, 16>([&](auto K) NL_INL {
-                constexpr int k = decltype(K)::value;
-                v[k] = nan_to_inf(v[k]);
-            });
         }
         sort_network<NS>(v);
         // ---- merge the LPP sorted runs: lane r ends up with ranks [r*NS, r*NS+NS) ----

@@ -81,6 +81,11 @@ struct nl_stack {
     bool last_used_fast = false;
     unsigned long long *d_counters = nullptr;  // [2]
     double *d_stat_partial = nullptr;          // [kStatBlocks*3]
+    // linear-fit cascade (stack_linfit.hip): ping-pong pixel lists + liveness masks, lazily allocated
+    unsigned *d_lf_list[2] = {nullptr, nullptr};
+    uint4 *d_lf_state[2] = {nullptr, nullptr};
+    unsigned *d_lf_count = nullptr;
+    bool lf_tried = false;
     void *d_ingest = nullptr;                  // raw FITS bytes / unaligned source frame, grown on demand
     size_t ingest_bytes = 0;
     // asynchronous uploads: pinned staging ring + copy stream (nl_stack_upload_frame_async)
@@ -127,6 +132,11 @@ static int destroy_impl(nl_stack_t *h)
     if (h->d_counters) (void)hipFree(h->d_counters);
     if (h->d_stat_partial) (void)hipFree(h->d_stat_partial);
     if (h->d_ingest) (void)hipFree(h->d_ingest);
+    for (int i = 0; i < 2; i++) {
+        if (h->d_lf_list[i]) (void)hipFree(h->d_lf_list[i]);
+        if (h->d_lf_state[i]) (void)hipFree(h->d_lf_state[i]);
+    }
+    if (h->d_lf_count) (void)hipFree(h->d_lf_count);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     for (int i = 0; i < kStageSlots; i++) {
         if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
@@ -456,8 +466,34 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         f.fb_list = h->d_fb_list;
         f.fb_count = h->d_fb_count;
         f.fb_capacity = (unsigned)h->npix;
-        NL_HIP(nl::launch_stack_linfit_fast(a, f, h->stream, &h->last_kernel));
-        NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
+        // cascade buffers (20 B per pixel, twice): without them the kernel runs as one stage
+        if (!h->lf_tried) {
+            h->lf_tried = true;
+            const size_t np = (size_t)h->npix;
+            bool ok = hipMalloc(&h->d_lf_count, sizeof(unsigned) * nl::kLinfitStages) == hipSuccess;
+            for (int i = 0; i < 2 && ok; i++)
+                ok = hipMalloc(&h->d_lf_list[i], sizeof(unsigned) * np) == hipSuccess &&
+                     hipMalloc(&h->d_lf_state[i], sizeof(uint4) * np) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError();
+                for (int i = 0; i < 2; i++) {
+                    if (h->d_lf_list[i]) { (void)hipFree(h->d_lf_list[i]); h->d_lf_list[i] = nullptr; }
+                    if (h->d_lf_state[i]) { (void)hipFree(h->d_lf_state[i]); h->d_lf_state[i] = nullptr; }
+                }
+                if (h->d_lf_count) { (void)hipFree(h->d_lf_count); h->d_lf_count = nullptr; }
+            }
+        }
+        nl::LinfitCascade cascade;
+        const nl::LinfitCascade *cas = nullptr;
+        if (h->d_lf_count && h->d_lf_state[1]) {
+            cascade.list[0] = h->d_lf_list[0]; cascade.list[1] = h->d_lf_list[1];
+            cascade.state[0] = h->d_lf_state[0]; cascade.state[1] = h->d_lf_state[1];
+            cascade.count = h->d_lf_count;
+            cascade.capacity = (unsigned)h->npix;
+            NL_HIP(hipMemsetAsync(h->d_lf_count, 0, sizeof(unsigned) * nl::kLinfitStages, h->stream));
+            cas = &cascade;
+        }
+        NL_HIP(nl::launch_stack_linfit_fast(a, f, cas, h->stream, &h->last_kernel, h->ev_dom1));
         int lanes = 0;
         size_t lds = 0;
         if (nl::exact_plan(mode, weighted, a.n_frames, a.n_pad, kListLanes, &lanes, &lds) != 0)

@@ -75,9 +75,19 @@ int coop_supported(int mode, bool weighted, int n_frames);
 hipError_t launch_stack_sigma_coop(int mode, const StackArgs &args, int grid, hipStream_t stream, const char **name);
 
 // ---- stack_linfit.hip (register-resident linear fit, bit-exact) ----
+// Cascade: a stage runs at most max_iters fit iterations; pixels that are not done are
+// appended to out_list together with their liveness mask (4 words) and continued by the
+// next stage in freshly packed waves (lists and states: npix entries each).
+struct LinfitCascade {
+    unsigned *list[2];            // ping-pong pixel lists
+    uint4 *state[2];              // liveness masks of the listed pixels
+    unsigned *count;              // device: [kLinfitStages] list lengths, zeroed per pass
+    unsigned capacity;
+};
+constexpr int kLinfitStages = 4;
 int linfit_fast_supported(int mode, int n_frames);
-hipError_t launch_stack_linfit_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
-                                    const char **name);
+hipError_t launch_stack_linfit_fast(const StackArgs &args, const FastArgs &fargs, const LinfitCascade *cascade,
+                                    hipStream_t stream, const char **name, hipEvent_t dominant_done);
 
 // ---- stack_mean.hip ----
 hipError_t launch_stack_mean(bool weighted, const StackArgs &args, hipStream_t stream,

@@ -44,16 +44,34 @@ __device__ __forceinline__ void forget_words(unsigned (&w)[NW])
 // would produce a lane mask in SGPRs per element
 __device__ __forceinline__ unsigned sign_bit(float x) { return (unsigned)__float_as_int(x) >> 31; }
 
-template <int NS>
-__global__ __launch_bounds__(256) void stack_linfit_fast_kernel(StackArgs p, FastArgs q)
+// CONT = false: first stage, the grid covers the tile.  CONT = true: continuation
+// stage, grid-stride over the pixels the previous stage handed over; their
+// liveness masks come from memory (the sorted column is re-created: sorting is
+// deterministic, so the mask positions still mean the same samples).
+struct LinfitStage {
+    const unsigned *in_list;  const unsigned *in_count;  const uint4 *in_state;  unsigned in_capacity;
+    unsigned *out_list;       unsigned *out_count;       uint4 *out_state;       unsigned out_capacity;
+    int max_iters;            // fit iterations this stage may run per pixel (0: unlimited)
+};
+
+template <int NS, bool CONT>
+__global__ __launch_bounds__(256) void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
 {
     constexpr int NW = (NS + 31) / 32;          // liveness words per pixel
-    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool on = pix < p.npix;
     const int lane = threadIdx.x & 63;
+    int c_lo = 0, c_hi = 0;
+    const int64_t limit = CONT ? (int64_t)min(*g.in_count, g.in_capacity) : p.npix;
+    const int64_t sweep = CONT ? (int64_t)gridDim.x * blockDim.x : limit;
+  for (int64_t wg_item = (int64_t)blockIdx.x * blockDim.x; wg_item < limit; wg_item += sweep) {
+    int N = p.n_frames;
+    asm volatile("" : "+s"(N));                 // per trip: keeps per-frame scalars out of the loop preheader
+    const int64_t item = wg_item + threadIdx.x;
+    const bool on = item < limit;
+    int64_t pix = item;
+    if (CONT) pix = on ? (int64_t)g.in_list[item] : 0;
     const unsigned boff = (unsigned)(on ? pix : 0) * 4u;
     float v[NS];
-    const int n = gather_sorted<NS, 32>(p.frames, p.stride, p.n_frames, boff, v);
+    const int n = gather_sorted<NS, 32>(p.frames, p.stride, N, boff, v);
 
     // The sorted column never changes; a sample's liveness is one bit of
     // live[].  Initially the n valid samples (positions 0..n-1) are alive.
@@ -66,6 +84,17 @@ __global__ __launch_bounds__(256) void stack_linfit_fast_kernel(StackArgs p, Fas
         const int c = min(max(n - 32 * w, 0), 32);
         live[w] = c >= 32 ? 0xFFFFFFFFu : ((1u << c) - 1u);
     });
+    int m_saved = n;
+    if constexpr (CONT) {
+        const uint4 st = g.in_state[on ? item : 0];
+        const unsigned w4[4] = {st.x, st.y, st.z, st.w};
+        m_saved = 0;
+        static_range<0, NW>([&](auto W) NL_INL {
+            constexpr int w = decltype(W)::value;
+            live[w] = w4[w];
+            m_saved += __popc(w4[w]);
+        });
+    }
     unsigned inf_any = 0;
     {
         int nn = n;
@@ -81,11 +110,13 @@ __global__ __launch_bounds__(256) void stack_linfit_fast_kernel(StackArgs p, Fas
     const bool to_exact = inf_any != 0;
 
     float res = p.ref_loc;
-    int c_lo = 0, c_hi = 0;
-    int m = n;                                  // surviving samples
+    int p_lo = 0, p_hi = 0;
+    int m = m_saved;                            // surviving samples
     bool active = on && n > 0 && !to_exact;
+    int iters = 0;
 
-    while (__any(active)) {
+    while (__any(active) && (g.max_iters == 0 || iters < g.max_iters)) {
+        iters++;
         const float fm = (float)m;
         const int mt = (active && m >= 1) ? m : 1;
         const float xm = p.xstat[2 * mt], xsd = p.xstat[2 * mt + 1];
@@ -169,8 +200,8 @@ __global__ __launch_bounds__(256) void stack_linfit_fast_kernel(StackArgs p, Fas
         });
 #undef NL_LF
         if (active) {
-            c_lo += (int)lo_n;
-            c_hi += (int)hi_n;
+            p_lo += (int)lo_n;
+            p_hi += (int)hi_n;
             const int left = (int)(lo_n + hi_n);
             res = ym;                                       // stack.go:911: mean of the last regression
             if (left == 0 || m < 3) active = false;
@@ -179,8 +210,24 @@ __global__ __launch_bounds__(256) void stack_linfit_fast_kernel(StackArgs p, Fas
         }
     }
 
-    if (on && !to_exact) p.out[pix] = res;
-    if (!on || to_exact) { c_lo = 0; c_hi = 0; }
+    // lanes that are still fitting after this stage's quota go to the next stage; the
+    // rejections they made so far are final and are counted here
+    const bool more = active;
+    if (on && !to_exact && !more) p.out[pix] = res;
+    if (on && !to_exact) { c_lo += p_lo; c_hi += p_hi; }
+    const unsigned long long mm = __ballot(more);
+    if (mm) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(g.out_count, (unsigned)__popcll(mm));
+        base = __shfl(base, 0, 64);
+        const unsigned slot = base + (unsigned)__popcll(mm & ((1ull << lane) - 1ull));
+        if (more && slot < g.out_capacity) {
+            g.out_list[slot] = (unsigned)pix;
+            unsigned w4[4] = {0u, 0u, 0u, 0u};
+            static_range<0, NW>([&](auto W) NL_INL { w4[decltype(W)::value] = live[decltype(W)::value]; });
+            g.out_state[slot] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+    }
     const unsigned long long em = __ballot(on && to_exact);
     if (em) {
         unsigned base = 0;
@@ -189,6 +236,7 @@ __global__ __launch_bounds__(256) void stack_linfit_fast_kernel(StackArgs p, Fas
         const unsigned slot = base + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
         if (on && to_exact && slot < q.fb_capacity) q.fb_list[slot] = (unsigned)pix;
     }
+  }
 
     __shared__ int s_lo[4], s_hi[4];
 #pragma unroll
@@ -213,23 +261,51 @@ int linfit_fast_supported(int mode, int n_frames)
 }
 
 template <int NS>
-static void launch_lf(const StackArgs &args, const FastArgs &f, unsigned blocks, hipStream_t stream)
+static void launch_lf(const StackArgs &args, const FastArgs &f, const LinfitCascade *c, unsigned blocks,
+                      hipStream_t stream, hipEvent_t dominant_done)
 {
-    hipLaunchKernelGGL(stack_linfit_fast_kernel<NS>, dim3(blocks), dim3(256), 0, stream, args, f);
+    LinfitStage g = {};
+    if (!c) {                                    // no cascade buffers: one stage, run to completion
+        hipLaunchKernelGGL((stack_linfit_fast_kernel<NS, false>), dim3(blocks), dim3(256), 0, stream, args, f, g);
+        if (dominant_done) (void)hipEventRecord(dominant_done, stream);
+        return;
+    }
+    // Fit iterations per stage.  The number a pixel needs varies a lot (8 on average, 20-26
+    // for the slowest lane of a wave): capping a stage and re-packing the unfinished pixels
+    // into full waves halves the lane-iterations, at the price of re-sorting those pixels.
+    static const int quota[kLinfitStages] = {6, 6, 8, 0};
+    for (int s = 0; s < kLinfitStages; s++) {
+        g.max_iters = quota[s];
+        g.in_list = s ? c->list[(s - 1) & 1] : nullptr;
+        g.in_state = s ? c->state[(s - 1) & 1] : nullptr;
+        g.in_count = s ? c->count + (s - 1) : nullptr;
+        g.in_capacity = c->capacity;
+        g.out_list = c->list[s & 1];
+        g.out_state = c->state[s & 1];
+        g.out_count = c->count + s;
+        g.out_capacity = c->capacity;
+        if (s == 0) {
+            hipLaunchKernelGGL((stack_linfit_fast_kernel<NS, false>), dim3(blocks), dim3(256), 0, stream, args, f, g);
+            if (dominant_done) (void)hipEventRecord(dominant_done, stream);
+        } else {
+            const unsigned gblocks = blocks < 8192u ? blocks : 8192u;
+            hipLaunchKernelGGL((stack_linfit_fast_kernel<NS, true>), dim3(gblocks), dim3(256), 0, stream, args, f, g);
+        }
+    }
 }
 
-hipError_t launch_stack_linfit_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
-                                    const char **name)
+hipError_t launch_stack_linfit_fast(const StackArgs &args, const FastArgs &fargs, const LinfitCascade *cascade,
+                                    hipStream_t stream, const char **name, hipEvent_t dominant_done)
 {
     const unsigned blocks = (unsigned)((args.npix + 255) / 256);
     const int n = args.n_frames;
-    if (n <= 8)        { *name = "stack_linfit_fast_kernel<8>";   launch_lf<8>(args, fargs, blocks, stream); }
-    else if (n <= 16)  { *name = "stack_linfit_fast_kernel<16>";  launch_lf<16>(args, fargs, blocks, stream); }
-    else if (n <= 32)  { *name = "stack_linfit_fast_kernel<32>";  launch_lf<32>(args, fargs, blocks, stream); }
-    else if (n <= 48)  { *name = "stack_linfit_fast_kernel<48>";  launch_lf<48>(args, fargs, blocks, stream); }
-    else if (n <= 64)  { *name = "stack_linfit_fast_kernel<64>";  launch_lf<64>(args, fargs, blocks, stream); }
-    else if (n <= 96)  { *name = "stack_linfit_fast_kernel<96>";  launch_lf<96>(args, fargs, blocks, stream); }
-    else               { *name = "stack_linfit_fast_kernel<128>"; launch_lf<128>(args, fargs, blocks, stream); }
+    if (n <= 8)        { *name = "stack_linfit_fast_kernel<8, false>";   launch_lf<8>(args, fargs, cascade, blocks, stream, dominant_done); }
+    else if (n <= 16)  { *name = "stack_linfit_fast_kernel<16, false>";  launch_lf<16>(args, fargs, cascade, blocks, stream, dominant_done); }
+    else if (n <= 32)  { *name = "stack_linfit_fast_kernel<32, false>";  launch_lf<32>(args, fargs, cascade, blocks, stream, dominant_done); }
+    else if (n <= 48)  { *name = "stack_linfit_fast_kernel<48, false>";  launch_lf<48>(args, fargs, cascade, blocks, stream, dominant_done); }
+    else if (n <= 64)  { *name = "stack_linfit_fast_kernel<64, false>";  launch_lf<64>(args, fargs, cascade, blocks, stream, dominant_done); }
+    else if (n <= 96)  { *name = "stack_linfit_fast_kernel<96, false>";  launch_lf<96>(args, fargs, cascade, blocks, stream, dominant_done); }
+    else               { *name = "stack_linfit_fast_kernel<128, false>"; launch_lf<128>(args, fargs, cascade, blocks, stream, dominant_done); }
     return hipGetLastError();
 }
 

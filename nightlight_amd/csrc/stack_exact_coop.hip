@@ -10,8 +10,8 @@
 //   quickselect qsort.go:94-126    a whole Hoare partition pass at once: the misplaced elements of
 //                                  both sides are listed with ballot + popcount and the pass's
 //                                  swaps are done in parallel (see coop_select)
-//   mean/stddev stats.go:246-261   the fp32 sums stay sequential (v_readlane feeds one add chain);
-//                                  differences and squares are computed 64 at a time
+//   mean/stddev stats.go:246-261   the fp32 sums stay sequential: a DPP wave-shift add chain, 64
+//                                  elements per step; differences and squares are computed 64 at a time
 //   winsorize   stack.go:646-672   the copy is clamped 64 samples at a time (ballot counts `changed`),
 //                                  its mean / stddev are the same sequential sums
 //   clip        stack.go:411-424   swap-with-last, same visiting order, clean stretches skipped 64 at a time
@@ -33,23 +33,34 @@ __device__ __forceinline__ void lds_fence()
     __syncthreads();      // single-wave workgroup: orders LDS writes before later reads
 }
 
-// sequential fp32 sum of t[0..n) in index order; x = per-lane slice loader
+// sequential fp32 sum of t[0..n) in index order; elem = per-lane slice loader, which must
+// deliver +0.0f past n (adding +0.0f leaves a running sum unchanged bit for bit: the sum
+// starts at +0.0f and can therefore never be -0.0f).
+//
+// 64 elements per step: lane l holds x[l]; "s[l] = s[l-1] + x[l]" is issued 63 times on
+// all lanes with a DPP wave shift (lane 0, whose source is out of range, is left alone).
+// After step t lanes 0..t hold their final prefix sums -- re-computing a final value from a
+// final neighbour gives the same bits -- so lane 63 ends with the chunk's sequential sum,
+// one VALU instruction per element.
+__device__ __forceinline__ float chain64(float carry, float x)
+{
+    float s = (threadIdx.x == 0) ? carry + x : x;
+#define NL_STEP "v_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+#define NL_STEP8 NL_STEP NL_STEP NL_STEP NL_STEP NL_STEP NL_STEP NL_STEP NL_STEP
+    asm volatile("s_nop 1\n\t" NL_STEP8 NL_STEP8 NL_STEP8 NL_STEP8 NL_STEP8 NL_STEP8 NL_STEP8
+                 NL_STEP NL_STEP NL_STEP NL_STEP NL_STEP NL_STEP NL_STEP
+                 : "+v"(s) : "v"(x));
+#undef NL_STEP8
+#undef NL_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
+}
+
 template <class F>
 __device__ __forceinline__ float seq_sum(int n, F &&elem)
 {
     float s = 0.0f;
     const int lane = threadIdx.x;
-    for (int base = 0; base < n; base += 64) {
-        const float x = elem(base + lane);              // lanes past n deliver garbage, never added
-        const int m = min(64, n - base);
-        int i = 0;
-        for (; i + 8 <= m; i += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i + u));
-        }
-        for (; i < m; i++) s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i));
-    }
+    for (int base = 0; base < n; base += 64) s = chain64(s, elem(base + lane));
     return s;
 }
 
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
                 const float mean = s / fn;
                 const float vs = seq_sum(n, [&](int i) {
                     const float d = (i < n ? a[i] : mean) - mean;
-                    return d * d;
+                    return i < n ? d * d : 0.0f;
                 });
                 const float var = vs / fn;
                 float sd = sqrt_like_go(var);
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
                         const float wmean = ws / fn;
                         const float wvs = seq_sum(n, [&](int i) {
                             const float d = (i < n ? wz[i] : wmean) - wmean;
-                            return d * d;
+                            return i < n ? d * d : 0.0f;
                         });
                         const float old = sd;
                         sd = 1.134f * sqrt_like_go(wvs / fn);

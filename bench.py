@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=0,
                     help="rows of the stack timed on the CPU (0 = auto, about 10-30 s)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--weighted", action="store_true",
+                    help="per-frame weights in [0.2, 1] (the shape of inverse-noise weights, stack.go:246-253)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank path)")
     ap.add_argument("--share-device", action="store_true",
@@ -59,7 +61,7 @@ def cpu_model():
     return "unknown CPU"
 
 
-def cpu_baseline(st, args, rows):
+def cpu_baseline(st, args, rows, weights=None):
     """Times the oracle (oracle/nl_oracle.c, a C restatement of the Go reference:
     same batching rule, one worker per host core) on the first `rows` rows."""
     import numpy as np
@@ -70,7 +72,8 @@ def cpu_baseline(st, args, rows):
         frames[i] = st.download_tile(i)[: rows * w]
     cores = os.cpu_count() or 1
     t0 = time.perf_counter()
-    rc, res, cl, ch, _ = oracle.stack_apply(args.mode, frames, None, args.kappa, args.kappa,
+    ow = None if args.mode in (0, 5) else weights          # median / linear fit take no weights (stack.go:158,188)
+    rc, res, cl, ch, _ = oracle.stack_apply(args.mode, frames, ow, args.kappa, args.kappa,
                                             0.0, num_cpu=cores)
     dt = time.perf_counter() - t0
     assert rc == 0
@@ -125,6 +128,10 @@ def main():
     total_rows = rows * world
     st = StackHandle(n, w, total_rows, row0=rank * rows, rows=rows, device=device)
     st.fill_synthetic()
+    weights = None
+    if args.weighted:
+        weights = np.array([0.2 + 0.8 * ((k * 37) % 101) / 100.0 for k in range(n)], np.float32)
+        st.set_weights(weights)
     counters = torch.zeros(2, dtype=torch.int64, device=comm_device)
 
     def step():
@@ -170,8 +177,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%d x %dx%d fp32 frames per GPU, %s kappa=%g, frames resident in HBM"
-                                   % (n, rows, w, MODE_NAMES[args.mode], args.kappa),
+            "config": {"workload": "%d x %dx%d fp32 frames per GPU, %s%s kappa=%g, frames resident in HBM"
+                                   % (n, rows, w, MODE_NAMES[args.mode], " (weighted)" if args.weighted else "",
+                                      args.kappa),
                        "frames": n, "width": w, "rows_per_gpu": rows, "mode": args.mode,
                        "sharding": "row tiles, %d rank(s); all-reduce of 2 int64 clip counters per pass" % world,
                        "clip_low": int(counters[0].item()) if dist is not None else cl,
@@ -193,12 +201,13 @@ def main():
                 cores = os.cpu_count() or 1
                 cpu_rows = max(8, min(rows, int(cores * 12 * 5.0e6 / (n * w))))
             cpu_rows = min(cpu_rows, rows)
-            base, res, cc = cpu_baseline(st, args, cpu_rows)
+            base, res, cc = cpu_baseline(st, args, cpu_rows, weights)
             # parity in the same run: the same strip through the C ABI vs the oracle.
             # Clip counters must be equal; values within the north star's 1e-5
             # (bit-exact for every kernel but the register-resident sigma one).
             with StackHandle(n, w, total_rows, row0=0, rows=cpu_rows, device=device) as strip:
                 strip.fill_synthetic()
+                strip.set_weights(weights)
                 got, gl, gh = strip.run(args.mode, args.kappa, args.kappa, 0.0)
                 got = got[: cpu_rows * w]
             ok = ~np.isnan(res) & (res != 0)

@@ -155,12 +155,16 @@ __device__ float coop_select_median(float *a, int *lpos, int *rfwd, int n)
 
 }  // namespace
 
-template <bool WINSOR>
+// W: weighted variants (stack.go:442-531, 710-829).  The weights live in their own column and
+// follow only the clip swaps -- quickselect permutes the samples, NOT the weights
+// (stack.go:487), and the weighted mean pairs them index by index all the same.
+template <bool WINSOR, bool W>
 __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
 {
     extern __shared__ float a[];
     float *wz = a + p.n_frames;                   // winsorized copy (WINSOR only)
-    int *lpos = reinterpret_cast<int *>(a + (WINSOR ? 2 : 1) * p.n_frames);   // partition scratch, 2 x n_frames
+    float *wt = a + (WINSOR ? 2 : 1) * p.n_frames;          // weights (W only)
+    int *lpos = reinterpret_cast<int *>(a + ((WINSOR ? 2 : 1) + (W ? 1 : 0)) * p.n_frames);   // partition scratch, 2 x n_frames
     int *rfwd = lpos + p.n_frames;
     const int lane = threadIdx.x;
     const int N = p.n_frames;
@@ -186,6 +190,7 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
             const unsigned long long m = __ballot(valid);
             const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
             if (valid) a[pos] = x;
+            if (W && valid) wt[pos] = p.weights[k];                   // stack.go:452-459
             n += __popcll(m);
         }
         lds_fence();
@@ -255,14 +260,24 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
                     if (found < 0) break;
                     const float g = a[found];
                     const float last = a[n - 1];
+                    float last_w = 0.0f;
+                    if (W) last_w = wt[n - 1];
                     if (g < lo) c_lo++; else c_hi++;
                     lds_fence();
-                    if (lane == 0) a[found] = last;
+                    if (lane == 0) { a[found] = last; if (W) wt[found] = last_w; }
                     lds_fence();
                     n--;
                     j = found;
                 }
-                if (n == before || n <= 1) { res = mean; break; }
+                if (n == before || n <= 1) {
+                    res = mean;                                   // stack.go:427-430: mean before this pass
+                    if constexpr (W) {                            // stack.go:514-522: weighted mean of the survivors
+                        const float sw = seq_sum(n, [&](int i) { return i < n ? a[i] * wt[i] : 0.0f; });
+                        const float ws = seq_sum(n, [&](int i) { return i < n ? wt[i] : 0.0f; });
+                        res = sw / ws;
+                    }
+                    break;
+                }
             }
         }
         if (lane == 0) p.out[pix] = res;
@@ -274,23 +289,37 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
     }
 }
 
+static size_t coop_columns(int mode, bool weighted)
+{
+    return (mode == NL_ST_WINSOR_SIGMA ? 2 : 1) + (weighted ? 1 : 0) + 2;      // samples (+copy) (+weights) + 2 scratch
+}
+
 int coop_supported(int mode, bool weighted, int n_frames)
 {
-    if (weighted) return 0;
-    if (mode == NL_ST_SIGMA) return (size_t)n_frames * 3 * sizeof(float) <= 64 * 1024 ? 1 : 0;
-    if (mode == NL_ST_WINSOR_SIGMA) return (size_t)n_frames * 4 * sizeof(float) <= 64 * 1024 ? 1 : 0;
-    return 0;
+    if (mode != NL_ST_SIGMA && mode != NL_ST_WINSOR_SIGMA) return 0;
+    return (size_t)n_frames * coop_columns(mode, weighted) * sizeof(float) <= 64 * 1024 ? 1 : 0;
 }
 
 hipError_t launch_stack_sigma_coop(int mode, const StackArgs &args, int grid, hipStream_t stream, const char **name)
 {
-    const size_t column = (size_t)args.n_frames * sizeof(float);
+    const bool weighted = args.weights != nullptr;
+    const size_t lds = (size_t)args.n_frames * sizeof(float) * coop_columns(mode, weighted);
     if (mode == NL_ST_WINSOR_SIGMA) {
-        *name = "stack_sigma_coop_kernel<true>";
-        hipLaunchKernelGGL(stack_sigma_coop_kernel<true>, dim3(grid), dim3(64), 4 * column, stream, args);
+        if (weighted) {
+            *name = "stack_sigma_coop_kernel<true, true>";
+            hipLaunchKernelGGL((stack_sigma_coop_kernel<true, true>), dim3(grid), dim3(64), lds, stream, args);
+        } else {
+            *name = "stack_sigma_coop_kernel<true, false>";
+            hipLaunchKernelGGL((stack_sigma_coop_kernel<true, false>), dim3(grid), dim3(64), lds, stream, args);
+        }
     } else {
-        *name = "stack_sigma_coop_kernel<false>";
-        hipLaunchKernelGGL(stack_sigma_coop_kernel<false>, dim3(grid), dim3(64), 3 * column, stream, args);
+        if (weighted) {
+            *name = "stack_sigma_coop_kernel<false, true>";
+            hipLaunchKernelGGL((stack_sigma_coop_kernel<false, true>), dim3(grid), dim3(64), lds, stream, args);
+        } else {
+            *name = "stack_sigma_coop_kernel<false, false>";
+            hipLaunchKernelGGL((stack_sigma_coop_kernel<false, false>), dim3(grid), dim3(64), lds, stream, args);
+        }
     }
     return hipGetLastError();
 }

@@ -145,11 +145,13 @@ def test_wave_per_pixel_exact_replay_is_bit_exact(nl, oracle, n):
     # (the fallback of the register-resident kernels); forced here for every pixel
     width, height = 37, 5
     frames = make_frames(n, width, height, seed=900 + n, ties=(n % 2 == 1))
+    weights = np.random.default_rng(n).uniform(0.2, 1.0, n).astype(np.float32)
     for mode in (2, 3):                   # sigma, winsorized sigma
         for kappa in (2.75, 1.0):
-            got, gc, want, wc = run_both(nl, oracle, mode, frames, width, height, None, kappa, kappa, exact=2)
-            assert same_values(got, want), "coop %s n=%d: %s" % (MODES[mode], n, describe_mismatch(got, want))
-            assert gc == wc
+            for w in (None, weights):     # weighted: the weights follow the clip swaps only (stack.go:487)
+                got, gc, want, wc = run_both(nl, oracle, mode, frames, width, height, w, kappa, kappa, exact=2)
+                assert same_values(got, want), "coop %s n=%d: %s" % (MODES[mode], n, describe_mismatch(got, want))
+                assert gc == wc
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 9, 25, 31, 33, 64, 65, 100, 128])

@@ -159,19 +159,24 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         float amax = fmaxf(fabsf(v[0]), fabsf(pick<ZONAL ? ZH : 0, NS>(v, n - 1)));
 
         while (__any(active)) {
+            // re-materialised per pass: otherwise the differences v[k] - c of every masked
+            // position are hoisted out of the loop (one register each -- 128 in the generic pass;
+            // the 24 of the zonal sigma pass are left alone)
+            float cz = c;
+            if constexpr (!ZONAL || WINSOR) asm volatile("" : "+v"(cz));
             const int cnt = b - a;
             const float fcnt = (float)cnt;
             float dz0 = 0.0f, dz1 = 0.0f, qz0 = 0.0f, qz1 = 0.0f;
             if constexpr (ZONAL) {
                 static_range<0, ZL>([&](auto K) NL_INL {
                     constexpr int k = decltype(K)::value;
-                    const float e = (k >= a) ? v[k] - c : 0.0f;
+                    const float e = (k >= a) ? v[k] - cz : 0.0f;
                     dz0 += e;
                     qz0 = __builtin_fmaf(e, e, qz0);
                 });
                 static_range<ZH, NS>([&](auto K) NL_INL {
                     constexpr int k = decltype(K)::value;
-                    const float e = (k < b) ? v[k] - c : 0.0f;
+                    const float e = (k < b) ? v[k] - cz : 0.0f;
                     dz1 += e;
                     qz1 = __builtin_fmaf(e, e, qz1);
                 });
@@ -184,8 +189,8 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                     const bool i1 = (unsigned)(k + 1 - a1) < (unsigned)cnt;
                     const bool i2 = (unsigned)(k + 2 - a1) < (unsigned)cnt;
                     const bool i3 = (unsigned)(k + 3 - a1) < (unsigned)cnt;
-                    const float e0 = i0 ? v[k + 0] - c : 0.0f, e1 = i1 ? v[k + 1] - c : 0.0f;
-                    const float e2 = i2 ? v[k + 2] - c : 0.0f, e3 = i3 ? v[k + 3] - c : 0.0f;
+                    const float e0 = i0 ? v[k + 0] - cz : 0.0f, e1 = i1 ? v[k + 1] - cz : 0.0f;
+                    const float e2 = i2 ? v[k + 2] - cz : 0.0f, e3 = i3 ? v[k + 3] - cz : 0.0f;
                     dz0 += e0; dz1 += e1; dz2 += e2; dz3 += e3;
                     qz0 = __builtin_fmaf(e0, e0, qz0); qz1 = __builtin_fmaf(e1, e1, qz1);
                     qz2 = __builtin_fmaf(e2, e2, qz2); qz3 = __builtin_fmaf(e3, e3, qz3);
@@ -244,28 +249,28 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                         // (checked below); the inner half enters unclamped through d_in / q_in
                         static_range<0, ZL>([&](auto K) NL_INL {
                             constexpr int k = decltype(K)::value;
-                            const float e = (k >= a) ? fmaxf(v[k], Lt) - c : 0.0f;
+                            const float e = (k >= a) ? fmaxf(v[k], Lt) - cz : 0.0f;
                             d0 += e; q0 = __builtin_fmaf(e, e, q0);
                         });
                         static_chunks<0, (WL - ZL) / 4, 2>([&](auto K) NL_INL {
                             constexpr int k = ZL + 4 * decltype(K)::value;
-                            const float e0 = fmaxf(v[k], Lt) - c, e1 = fmaxf(v[k + 1], Lt) - c;
-                            const float e2 = fmaxf(v[k + 2], Lt) - c, e3 = fmaxf(v[k + 3], Lt) - c;
+                            const float e0 = fmaxf(v[k], Lt) - cz, e1 = fmaxf(v[k + 1], Lt) - cz;
+                            const float e2 = fmaxf(v[k + 2], Lt) - cz, e3 = fmaxf(v[k + 3], Lt) - cz;
                             d0 += e0; d1 += e1; d2 += e2; d3 += e3;
                             q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
                             q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
                         });
                         static_chunks<0, (ZH - WH) / 4, 2>([&](auto K) NL_INL {
                             constexpr int k = WH + 4 * decltype(K)::value;
-                            const float e0 = fminf(v[k], Ht) - c, e1 = fminf(v[k + 1], Ht) - c;
-                            const float e2 = fminf(v[k + 2], Ht) - c, e3 = fminf(v[k + 3], Ht) - c;
+                            const float e0 = fminf(v[k], Ht) - cz, e1 = fminf(v[k + 1], Ht) - cz;
+                            const float e2 = fminf(v[k + 2], Ht) - cz, e3 = fminf(v[k + 3], Ht) - cz;
                             d0 += e0; d1 += e1; d2 += e2; d3 += e3;
                             q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
                             q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
                         });
                         static_range<ZH, NS>([&](auto K) NL_INL {
                             constexpr int k = decltype(K)::value;
-                            const float e = (k < b) ? fminf(v[k], Ht) - c : 0.0f;
+                            const float e = (k < b) ? fminf(v[k], Ht) - cz : 0.0f;
                             d1 += e; q1 = __builtin_fmaf(e, e, q1);
                         });
                         d2 += d_in; q2 += q_in;
@@ -277,10 +282,10 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                             const bool i1 = (unsigned)(k + 1 - a4) < (unsigned)cnt;
                             const bool i2 = (unsigned)(k + 2 - a4) < (unsigned)cnt;
                             const bool i3 = (unsigned)(k + 3 - a4) < (unsigned)cnt;
-                            const float e0 = i0 ? __builtin_amdgcn_fmed3f(v[k + 0], Lt, Ht) - c : 0.0f;
-                            const float e1 = i1 ? __builtin_amdgcn_fmed3f(v[k + 1], Lt, Ht) - c : 0.0f;
-                            const float e2 = i2 ? __builtin_amdgcn_fmed3f(v[k + 2], Lt, Ht) - c : 0.0f;
-                            const float e3 = i3 ? __builtin_amdgcn_fmed3f(v[k + 3], Lt, Ht) - c : 0.0f;
+                            const float e0 = i0 ? __builtin_amdgcn_fmed3f(v[k + 0], Lt, Ht) - cz : 0.0f;
+                            const float e1 = i1 ? __builtin_amdgcn_fmed3f(v[k + 1], Lt, Ht) - cz : 0.0f;
+                            const float e2 = i2 ? __builtin_amdgcn_fmed3f(v[k + 2], Lt, Ht) - cz : 0.0f;
+                            const float e3 = i3 ? __builtin_amdgcn_fmed3f(v[k + 3], Lt, Ht) - cz : 0.0f;
                             d0 += e0; d1 += e1; d2 += e2; d3 += e3;
                             q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
                             q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);

@@ -323,7 +323,7 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
             // WIDE: re-materialised per pass, otherwise the 120 differences v[k] - c of the
             // wide zone are hoisted out of the loop and cost 120 registers
             float cz = c;
-            if constexpr (WIDE) asm volatile("" : "+v"(cz));
+            if constexpr (WIDE || !ZONAL) asm volatile("" : "+v"(cz));
             const int cnt = b - a;
             const float fcnt = (float)cnt;
             float dz = 0.0f, qz = 0.0f;

@@ -546,9 +546,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
             if (err == hipSuccess) err = hipEventRecord(hh->ev_join, hh->side_stream);
             k->err = err;
         };
-        int fast_grid = 0;
         if (a.n_frames <= 128)
-            NL_HIP(nl::launch_stack_sigma_fast(a, f, &fast_grid, h->stream, &h->last_kernel, h->ev_dom1,
+            NL_HIP(nl::launch_stack_sigma_fast(a, f, h->stream, &h->last_kernel, h->ev_dom1,
                                                mode == NL_ST_WINSOR_SIGMA, after, &fork));
         else   // 129..512 frames: 2 or 4 lanes per pixel
             NL_HIP(nl::launch_stack_sigma_ml(a, f, h->stream, &h->last_kernel, h->ev_dom1,

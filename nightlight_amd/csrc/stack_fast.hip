@@ -515,11 +515,10 @@ static void launch_sized(const StackArgs &args, const FastArgs &fargs, hipStream
     else               launch_pair<128, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
 }
 
-hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, int *blocks_used,
-                                   hipStream_t stream, const char **name, hipEvent_t dominant_done,
+hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
+                                   const char **name, hipEvent_t dominant_done,
                                    bool winsor, AfterDominant after, void *user)
 {
-    *blocks_used = 0;
     if (winsor) launch_sized<true>(args, fargs, stream, name, dominant_done, after, user);
     else        launch_sized<false>(args, fargs, stream, name, dominant_done, after, user);
     return hipGetLastError();

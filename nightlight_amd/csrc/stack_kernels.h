@@ -60,8 +60,8 @@ hipError_t launch_stack_median_fast(const StackArgs &args, hipStream_t stream, c
 // after_dominant(user) is called between the launch of the dominant (zonal) kernel and
 // the generic pass, so the caller can start work that only depends on the former
 typedef void (*AfterDominant)(void *user);
-hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, int *blocks_used,
-                                   hipStream_t stream, const char **name, hipEvent_t dominant_done,
+hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
+                                   const char **name, hipEvent_t dominant_done,
                                    bool winsor, AfterDominant after_dominant, void *user);
 
 // ---- stack_fast_ml.hip (129..512 frames, 2 or 4 lanes per pixel) ----
@@ -113,12 +113,6 @@ hipError_t launch_fill_synthetic(float *frames, int64_t stride, int n_frames, in
                                  hipStream_t stream);
 
 // ---- frame_stats.hip ----
-struct FrameStatsOut {            // device scratch written by the stats kernels
-    float mn, mx;
-    double sum;
-    double sumsq;
-    double noise_sum;
-};
 hipError_t launch_min_sum_max(const float *data, int64_t n, double *partial /*[blocks][3]*/,
                               int blocks, hipStream_t stream);
 hipError_t launch_variance(const float *data, int64_t n, float mean, double *partial /*[blocks]*/,

@@ -129,28 +129,23 @@ __global__ __launch_bounds__(256) void stack_linfit_fast_kernel(StackArgs p, Fas
             s = __fadd_rn(s, __fmul_rn(v[k], NL_LF(k)));
         });
         const float ym = s / fm;
-        float vs = 0.0f;
+        // ---- variance of the ys and the correlation sum (stats.go:573-579; divisor n+1,
+        // quirk Q5) in one pass: both only need ymean, and each accumulator still sees its
+        // terms in index order ----
+        float vs = 0.0f, corr = 0.0f, fi = 0.0f;
         forget_words<NW>(live);
-        static_chunks<0, NS, 16>([&](auto K) NL_INL {
-            constexpr int k = decltype(K)::value;
-            const float d = __fsub_rn(v[k], ym);
-            const float dd = __fmul_rn(d, d);
-            vs = __fadd_rn(vs, __fmul_rn(dd, NL_LF(k)));
-        });
-        const float ysd = sqrt_go(vs / fm);
-        // ---- correlation, stats.go:573-579 (divisor n+1, quirk Q5) ----
-        float corr = 0.0f, fi = 0.0f;
-        forget_words<NW>(live);
-        const float ym2 = opaque_f(ym);
         static_chunks<0, NS, 16>([&](auto K) NL_INL {
             constexpr int k = decltype(K)::value;
             const float lf = NL_LF(k);
+            const float dy = __fsub_rn(v[k], ym);
+            const float dd = __fmul_rn(dy, dy);
+            vs = __fadd_rn(vs, __fmul_rn(dd, lf));
             const float dx = __fsub_rn(fi, xm);
-            const float dy = __fsub_rn(v[k], ym2);
             const float t = __fmul_rn(dx, dy);
             corr = __fadd_rn(corr, __fmul_rn(t, lf));
             fi += lf;                                            // index among the survivors
         });
+        const float ysd = sqrt_go(vs / fm);
         float den = __fmul_rn(xsd, ysd);
         den = __fmul_rn(den, __fadd_rn(fm, 1.0f));
         corr = corr / den;

@@ -453,9 +453,14 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
         h->last_has_counters = false;
     } else if (!h->force_exact && mode == NL_ST_MEDIAN && nl::fast_supported(mode, weighted, a.n_frames)) {
-        // register-resident sorting network: bit-exact, nothing to hand over
-        NL_HIP(nl::launch_stack_median_fast(a, h->stream, &h->last_kernel));
-        NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
+        // register-resident sorting network, bit-exact; pixels with many missing samples are
+        // handed from the pruned-network kernel to the full-sort one
+        nl::FastArgs f;
+        memset(&f, 0, sizeof f);
+        f.gen_list = h->d_gen_list;                 // nullptr for huge tiles: full sort everywhere
+        f.gen_count = h->d_fb_count + 1;
+        f.gen_capacity = (unsigned)h->npix;
+        NL_HIP(nl::launch_stack_median_fast(a, f, h->stream, &h->last_kernel, h->ev_dom1));
         h->last_has_counters = false;
         h->last_used_fast = false;
     } else if (!h->force_exact && h->d_fb_list && nl::linfit_fast_supported(mode, a.n_frames)) {

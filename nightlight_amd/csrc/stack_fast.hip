@@ -40,21 +40,73 @@ namespace nl {
 
 // StackMedian (stack.go:274-303): the median is order independent, so the
 // sorted register column gives it exactly (qsort.go:68-82: odd n -> middle,
-// even n -> 0.5*(lower+upper)).  Bit-exact, no hand-over lists.
-template <int NS>
-__global__ __launch_bounds__(256) void stack_median_fast_kernel(StackArgs p)
+// even n -> 0.5*(lower+upper)).  Bit-exact.
+// WINDOW = true: grid covers the tile.  Only the ranks the median can occupy
+//   while at most kMedianPad samples are missing need to be exact, the rest of
+//   the network is pruned (ZonalNetwork: ~17 % fewer comparators) and the lookup
+//   scans 10 registers instead of all; lanes with more missing samples go to
+//   the hand-over list.
+// WINDOW = false: full sort, any number of missing samples; over the whole tile
+//   (small networks) or grid-stride over the hand-over list.
+constexpr int kMedianPad = 16;
+
+template <int NS, bool WINDOW>
+__global__ __launch_bounds__(256) void stack_median_fast_kernel(StackArgs p, FastArgs q)
 {
-    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool on = pix < p.npix;
-    const unsigned boff = (unsigned)(on ? pix : 0) * 4u;
-    float v[NS];
-    const int n = gather_sorted<NS>(p.frames, p.stride, p.n_frames, boff, v);
-    const int kk = n >> 1;
-    const float upper = pick<0, NS>(v, kk);
-    const float lower = pick<0, NS>(v, kk > 0 ? kk - 1 : 0);
-    float res = (n & 1) ? upper : 0.5f * (lower + upper);
-    if (n == 0) res = p.ref_loc;
-    if (on) p.out[pix] = res;
+    constexpr int W0 = WINDOW ? (NS - kMedianPad) / 2 - 1 : 0, W1 = WINDOW ? NS / 2 + 1 : NS;
+    using Sorter = std::conditional_t<WINDOW, ZonalSort<0, W0, W1, NS>, FullSort>;
+    const bool listed = !WINDOW && q.in_list != nullptr;
+    const int64_t limit = listed ? (int64_t)min(*q.in_count, q.in_capacity) : p.npix;
+    const int64_t sweep = listed ? (int64_t)gridDim.x * blockDim.x : limit;
+    const int lane = threadIdx.x & 63;
+    // (the windowed instantiation is a single trip; saying so keeps the compiler from
+    // overlapping two trips' columns in registers)
+    for (int64_t wg_item = (int64_t)blockIdx.x * blockDim.x; wg_item < limit; wg_item += sweep) {
+        int N = p.n_frames;
+        asm volatile("" : "+s"(N));              // per trip: keeps the per-frame scalars out of the loop preheader
+        const int64_t item = wg_item + threadIdx.x;
+        const bool on = item < limit;
+        int64_t pix = item;
+        if (listed) pix = on ? (int64_t)q.in_list[item] : 0;
+        const unsigned boff = (unsigned)(on ? pix : 0) * 4u;
+        float v[NS];
+        const int n = gather_sorted<NS, 16, Sorter>(p.frames, p.stride, N, boff, v);
+        const int kk = n >> 1;
+        bool hand_over = false;
+        float upper, lower;
+        if constexpr (WINDOW) {
+            hand_over = on && n < NS - kMedianPad;          // kk-1 >= W0 and kk < W1 otherwise
+            upper = pick<W0, W1>(v, kk);
+            lower = pick<W0, W1>(v, kk - 1);
+        } else {
+            upper = pick<0, NS>(v, kk);
+            lower = pick<0, NS>(v, kk > 0 ? kk - 1 : 0);
+        }
+        float res = (n & 1) ? upper : 0.5f * (lower + upper);
+        if (n == 0) res = p.ref_loc;
+        if constexpr (WINDOW) {
+            // Unconditional buffer store; lanes that must not write get an out-of-range offset,
+            // which the hardware drops.  (A store under `if (on)` makes the compiler keep a
+            // second copy of the column: 262 instead of 151 registers at NS = 128.)
+            const __amdgpu_buffer_rsrc_t ors =
+                __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(p.npix * 4), 0x00020000);     // npix < 2^29 (dispatch)
+            const unsigned so = (on && !hand_over) ? (unsigned)pix * 4u : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(res), ors, (int)so, 0, 0);
+        } else {
+            if (on) p.out[pix] = res;
+        }
+        if constexpr (WINDOW) {
+            const unsigned long long gm = __ballot(hand_over);
+            if (gm) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(q.gen_count, (unsigned)__popcll(gm));
+                base = __shfl(base, 0, 64);
+                const unsigned slot = base + (unsigned)__popcll(gm & ((1ull << lane) - 1ull));
+                if (hand_over && slot < q.gen_capacity) q.gen_list[slot] = (unsigned)pix;
+            }
+            break;
+        }
+    }
 }
 
 // ZONAL = true : grid covers the tile, lane = pixel blockIdx*256+thread;
@@ -428,24 +480,49 @@ int fast_supported(int mode, bool weighted, int n_frames)
 }
 
 template <int NS>
-static void launch_median(const StackArgs &args, unsigned blocks, hipStream_t stream)
+static void launch_median(const StackArgs &args, const FastArgs &fargs, unsigned blocks, hipStream_t stream,
+                          const char **name, hipEvent_t dominant_done)
 {
-    hipLaunchKernelGGL(stack_median_fast_kernel<NS>, dim3(blocks), dim3(256), 0, stream, args);
+    static const std::string names[2] = {"stack_median_fast_kernel<" + std::to_string(NS) + ", false>",
+                                         "stack_median_fast_kernel<" + std::to_string(NS) + ", true>"};
+    FastArgs f = fargs;
+    f.in_list = nullptr;
+    f.in_count = nullptr;
+    f.in_capacity = 0;
+    const bool window = NS >= 32 && args.n_frames > NS - kMedianPad && fargs.gen_list != nullptr &&
+                        args.npix < ((int64_t)1 << 29);
+    if constexpr (NS >= 32) {
+        if (window) {
+            *name = names[1].c_str();
+            hipLaunchKernelGGL((stack_median_fast_kernel<NS, true>), dim3(blocks), dim3(256), 0, stream, args, f);
+            if (dominant_done) (void)hipEventRecord(dominant_done, stream);
+            f.in_list = fargs.gen_list;
+            f.in_count = fargs.gen_count;
+            f.in_capacity = fargs.gen_capacity;
+            const unsigned gblocks = blocks < kGenericGrid ? blocks : kGenericGrid;
+            hipLaunchKernelGGL((stack_median_fast_kernel<NS, false>), dim3(gblocks), dim3(256), 0, stream, args, f);
+            return;
+        }
+    }
+    *name = names[0].c_str();
+    hipLaunchKernelGGL((stack_median_fast_kernel<NS, false>), dim3(blocks), dim3(256), 0, stream, args, f);
+    if (dominant_done) (void)hipEventRecord(dominant_done, stream);
 }
 
-hipError_t launch_stack_median_fast(const StackArgs &args, hipStream_t stream, const char **name)
+hipError_t launch_stack_median_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
+                                    const char **name, hipEvent_t dominant_done)
 {
     const unsigned blocks = (unsigned)((args.npix + 255) / 256);
     const int n = args.n_frames;
-    if (n <= 8)        { *name = "stack_median_fast_kernel<8>";   launch_median<8>(args, blocks, stream); }
-    else if (n <= 16)  { *name = "stack_median_fast_kernel<16>";  launch_median<16>(args, blocks, stream); }
-    else if (n <= 32)  { *name = "stack_median_fast_kernel<32>";  launch_median<32>(args, blocks, stream); }
-    else if (n <= 48)  { *name = "stack_median_fast_kernel<48>";  launch_median<48>(args, blocks, stream); }
-    else if (n <= 64)  { *name = "stack_median_fast_kernel<64>";  launch_median<64>(args, blocks, stream); }
-    else if (n <= 80)  { *name = "stack_median_fast_kernel<80>";  launch_median<80>(args, blocks, stream); }
-    else if (n <= 96)  { *name = "stack_median_fast_kernel<96>";  launch_median<96>(args, blocks, stream); }
-    else if (n <= 112) { *name = "stack_median_fast_kernel<112>"; launch_median<112>(args, blocks, stream); }
-    else               { *name = "stack_median_fast_kernel<128>"; launch_median<128>(args, blocks, stream); }
+    if (n <= 8)        launch_median<8>(args, fargs, blocks, stream, name, dominant_done);
+    else if (n <= 16)  launch_median<16>(args, fargs, blocks, stream, name, dominant_done);
+    else if (n <= 32)  launch_median<32>(args, fargs, blocks, stream, name, dominant_done);
+    else if (n <= 48)  launch_median<48>(args, fargs, blocks, stream, name, dominant_done);
+    else if (n <= 64)  launch_median<64>(args, fargs, blocks, stream, name, dominant_done);
+    else if (n <= 80)  launch_median<80>(args, fargs, blocks, stream, name, dominant_done);
+    else if (n <= 96)  launch_median<96>(args, fargs, blocks, stream, name, dominant_done);
+    else if (n <= 112) launch_median<112>(args, fargs, blocks, stream, name, dominant_done);
+    else               launch_median<128>(args, fargs, blocks, stream, name, dominant_done);
     return hipGetLastError();
 }
 

@@ -463,6 +463,12 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         NL_HIP(nl::launch_stack_median_fast(a, f, h->stream, &h->last_kernel, h->ev_dom1));
         h->last_has_counters = false;
         h->last_used_fast = false;
+    } else if (!h->force_exact && mode == NL_ST_MEDIAN && nl::fast_ml_supported(mode, weighted, a.n_frames, a.npix)) {
+        // 129..512 frames: 2 or 4 lanes per pixel, bit-exact
+        NL_HIP(nl::launch_stack_median_ml(a, h->stream, &h->last_kernel));
+        NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
+        h->last_has_counters = false;
+        h->last_used_fast = false;
     } else if (!h->force_exact && h->d_fb_list && nl::linfit_fast_supported(mode, a.n_frames)) {
         // register-resident linear fit: bit-exact (sums run in sorted order);
         // only pixels with an infinite sample are replayed by the LDS kernel

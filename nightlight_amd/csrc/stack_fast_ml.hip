@@ -158,6 +158,79 @@ __device__ __forceinline__ float pick_rank(const float (&v)[NS], int g, int role
 }
 
 // ZONAL / generic exactly as in stack_fast.hip; LPP lanes per pixel.
+// Gather one pixel's frames into the LPP lanes that share it (128 per lane), sort every
+// lane's column and merge the runs: afterwards lane r holds global ranks [r*NS, r*NS+NS)
+// (+Inf for missing samples at the top).  Returns the number of valid samples of the pixel.
+// ENDS_ONLY: the last merge orders only the KEEP lowest / highest ranks of every lane.
+template <int LPP, int NS, bool ENDS_ONLY>
+__device__ __forceinline__ int ml_gather_sorted(const float *frames, int64_t stride, int N, bool on, int64_t pix,
+                                                int role, float (&v)[NS])
+{
+int nan_cnt = 0;
+{
+        // Frames are dealt round-robin: lane role r takes frames r, r+LPP, ...
+        // (any split works, the column is sorted afterwards).  Buffer loads: one
+        // scalar descriptor per register index k covering frames k*LPP .. k*LPP+LPP-1,
+        // per-lane byte offset = pixel + role * frame.  The descriptor's size is
+        // cut at the last existing frame, so a lane whose frame k*LPP+role does
+        // not exist reads out of range -- the hardware returns 0 without touching
+        // memory -- and the position is marked missing below.  No per-lane
+        // addresses, no branches; descriptors are scalar work.
+        int frame_bytes = (int)(stride * (int64_t)sizeof(float));           // LPP*frame_bytes < 2^31 (dispatch)
+        // opaque per trip: otherwise the 128 descriptors are hoisted out of the
+        // item loop as loop invariants and spilled
+        asm volatile("" : "+s"(frame_bytes));
+        const int voff = (int)((unsigned)(on ? pix : 0) * 4u) + role * frame_bytes;
+        static_chunks<0, NS, 4>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            const int avail = min(max(N - k * LPP, 0), LPP);                // frames this descriptor covers
+            const char *gb = reinterpret_cast<const char *>(frames) + (int64_t)(k * LPP) * frame_bytes;
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gb), 0, avail * frame_bytes, 0x00020000);
+            v[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
+        });
+        // frame k*LPP+role >= N: missing (NaN).  Only k >= KPAD0 can be affected:
+        // this kernel is used for N > NT/2.
+        constexpr int KPAD0 = NS / 2;
+        int lastp = opaque(N - 1) - role;
+        static_chunks<KPAD0, NS, 8>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            if constexpr ((k & 7) == 0) lastp = opaque(lastp);
+            const int pad = (lastp - k * LPP) >> 31;                           // all ones -> NaN
+            v[k] = __int_as_float(__float_as_int(v[k]) | pad);
+        });
+        // clean waves skip the NaN count (see gather_sorted in fast_common.hpp)
+        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+        static_chunks<0, NS / 4, 8>([&](auto K) NL_INL {
+            constexpr int k = 4 * decltype(K)::value;
+            t0 += v[k]; t1 += v[k + 1]; t2 += v[k + 2]; t3 += v[k + 3];
+        });
+        const float total = (t0 + t1) + (t2 + t3);
+        if (__any(!(__builtin_fabsf(total) < __builtin_inff()))) {
+            static_chunks<0, NS, 8>([&](auto K) NL_INL {
+                constexpr int k = decltype(K)::value;
+                nan_cnt = opaque(nan_cnt - ((0x7f800000 - (__float_as_int(v[k]) & 0x7fffffff)) >> 31));
+                asm volatile("v_min_f32 %0, %0, %1" : "+v"(v[k]) : "v"(__builtin_inff()));   // NaN -> +Inf in place
+            });
+        }
+    }
+    sort_network<NS>(v);
+    // ---- merge the LPP sorted runs: lane r ends up with ranks [r*NS, r*NS+NS) ----
+    // (zonal: the final half-cleaners only order the ends of each lane, see half_clean_ends)
+    constexpr int KEEP = 16;
+    static_assert(kZone + kPadMax <= KEEP, "zones must lie inside the sorted ends");
+    cross_stage<NS, kSwap1, true>(v, (role & 1) == 0);
+    if constexpr (ENDS_ONLY && LPP == 2) half_clean_ends<NS, NS / 2, KEEP>(v);
+    else                             half_clean<NS, NS / 2>(v);
+    if constexpr (LPP == 4) {
+        cross_stage<NS, kMirror, true>(v, role < 2);
+        cross_stage<NS, kSwap1, false>(v, (role & 1) == 0);
+        if constexpr (ENDS_ONLY) half_clean_ends<NS, NS / 2, KEEP>(v);
+        else                 half_clean<NS, NS / 2>(v);
+    }
+    return quad_sum<LPP>(NS - nan_cnt);
+}
+
 // WIDE (zonal only): for frame counts well below LPP*128.  The unused positions sort
 // to the top as +Inf, so the last lanes hold nothing but padding and the high
 // zone has to reach down to the last real samples: it covers a whole lane
@@ -194,71 +267,8 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
         int64_t pix = item;
         if (listed) pix = on ? (int64_t)q.in_list[item] : 0;
 
-        // ---- gather ----
         float v[NS];
-        int nan_cnt = 0;
-        {
-            // Frames are dealt round-robin: lane role r takes frames r, r+LPP, ...
-            // (any split works, the column is sorted afterwards).  Buffer loads: one
-            // scalar descriptor per register index k covering frames k*LPP .. k*LPP+LPP-1,
-            // per-lane byte offset = pixel + role * frame.  The descriptor's size is
-            // cut at the last existing frame, so a lane whose frame k*LPP+role does
-            // not exist reads out of range -- the hardware returns 0 without touching
-            // memory -- and the position is marked missing below.  No per-lane
-            // addresses, no branches; descriptors are scalar work.
-            int frame_bytes = (int)(p.stride * (int64_t)sizeof(float));           // LPP*frame_bytes < 2^31 (dispatch)
-            // opaque per trip: otherwise the 128 descriptors are hoisted out of the
-            // item loop as loop invariants and spilled
-            asm volatile("" : "+s"(frame_bytes));
-            const int voff = (int)((unsigned)(on ? pix : 0) * 4u) + role * frame_bytes;
-            static_chunks<0, NS, 4>([&](auto K) NL_INL {
-                constexpr int k = decltype(K)::value;
-                const int avail = min(max(N - k * LPP, 0), LPP);                // frames this descriptor covers
-                const char *gb = reinterpret_cast<const char *>(p.frames) + (int64_t)(k * LPP) * frame_bytes;
-                const __amdgpu_buffer_rsrc_t rs =
-                    __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gb), 0, avail * frame_bytes, 0x00020000);
-                v[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
-            });
-            // frame k*LPP+role >= N: missing (NaN).  Only k >= KPAD0 can be affected:
-            // this kernel is used for N > NT/2.
-            constexpr int KPAD0 = NS / 2;
-            int lastp = opaque(N - 1) - role;
-            static_chunks<KPAD0, NS, 8>([&](auto K) NL_INL {
-                constexpr int k = decltype(K)::value;
-                if constexpr ((k & 7) == 0) lastp = opaque(lastp);
-                const int pad = (lastp - k * LPP) >> 31;                           // all ones -> NaN
-                v[k] = __int_as_float(__float_as_int(v[k]) | pad);
-            });
-            // clean waves skip the NaN count (see gather_sorted in fast_common.hpp)
-            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
-            static_chunks<0, NS / 4, 8>([&](auto K) NL_INL {
-                constexpr int k = 4 * decltype(K)::value;
-                t0 += v[k]; t1 += v[k + 1]; t2 += v[k + 2]; t3 += v[k + 3];
-            });
-            const float total = (t0 + t1) + (t2 + t3);
-            if (__any(!(__builtin_fabsf(total) < __builtin_inff()))) {
-                static_chunks<0, NS, 8>([&](auto K) NL_INL {
-                    constexpr int k = decltype(K)::value;
-                    nan_cnt = opaque(nan_cnt - ((0x7f800000 - (__float_as_int(v[k]) & 0x7fffffff)) >> 31));
-                    asm volatile("v_min_f32 %0, %0, %1" : "+v"(v[k]) : "v"(__builtin_inff()));   // NaN -> +Inf in place
-                });
-            }
-        }
-        sort_network<NS>(v);
-        // ---- merge the LPP sorted runs: lane r ends up with ranks [r*NS, r*NS+NS) ----
-        // (zonal: the final half-cleaners only order the ends of each lane, see half_clean_ends)
-        constexpr int KEEP = 16;
-        static_assert(kZone + kPadMax <= KEEP, "zones must lie inside the sorted ends");
-        cross_stage<NS, kSwap1, true>(v, (role & 1) == 0);
-        if constexpr (ZONAL && !WIDE && LPP == 2) half_clean_ends<NS, NS / 2, KEEP>(v);
-        else                             half_clean<NS, NS / 2>(v);
-        if constexpr (LPP == 4) {
-            cross_stage<NS, kMirror, true>(v, role < 2);
-            cross_stage<NS, kSwap1, false>(v, (role & 1) == 0);
-            if constexpr (ZONAL && !WIDE) half_clean_ends<NS, NS / 2, KEEP>(v);
-            else                 half_clean<NS, NS / 2>(v);
-        }
-        const int n = quad_sum<LPP>(NS - nan_cnt);
+        const int n = ml_gather_sorted<LPP, NS, ZONAL && !WIDE>(p.frames, p.stride, N, on, pix, role, v);
 
         bool to_exact = false;
         float res = p.ref_loc;
@@ -569,11 +579,48 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
     }
 }
 
+// StackMedian (stack.go:274-303) for 129..512 frames: the merged column gives the median
+// exactly (order independent); both middle ranks are looked up over whole lanes, so any
+// number of missing samples is fine and nothing is handed over.
+template <int LPP>
+__global__ __launch_bounds__(256) void stack_median_ml_kernel(StackArgs p)
+{
+    constexpr int NS = kMlNS;
+    const int role = threadIdx.x % LPP;
+    const int64_t item = (int64_t)blockIdx.x * (blockDim.x / LPP) + threadIdx.x / LPP;
+    const bool on = item < p.npix;
+    int N = p.n_frames;
+    asm volatile("" : "+s"(N));
+    float v[NS];
+    const int n = ml_gather_sorted<LPP, NS, false>(p.frames, p.stride, N, on, item, role, v);
+    const int kk = n >> 1;
+    const float upper = pick_rank<LPP, NS, NS, NS>(v, kk, role, 0);
+    const float lower = pick_rank<LPP, NS, NS, NS>(v, kk > 0 ? kk - 1 : 0, role, 0);
+    float res = (n & 1) ? upper : 0.5f * (lower + upper);          // qsort.go:73-81
+    if (n == 0) res = p.ref_loc;
+    if (on && role == 0) p.out[item] = res;
+}
+
+hipError_t launch_stack_median_ml(const StackArgs &args, hipStream_t stream, const char **name)
+{
+    if (args.n_frames <= 2 * kMlNS) {
+        *name = "stack_median_ml_kernel<2>";
+        const unsigned blocks = (unsigned)((args.npix + 127) / 128);
+        hipLaunchKernelGGL(stack_median_ml_kernel<2>, dim3(blocks), dim3(256), 0, stream, args);
+    } else {
+        *name = "stack_median_ml_kernel<4>";
+        const unsigned blocks = (unsigned)((args.npix + 63) / 64);
+        hipLaunchKernelGGL(stack_median_ml_kernel<4>, dim3(blocks), dim3(256), 0, stream, args);
+    }
+    return hipGetLastError();
+}
+
 int fast_ml_supported(int mode, bool weighted, int n_frames, int64_t npix)
 {
     // 4 frames of the tile must be addressable with a 31-bit buffer offset
-    return ((mode == NL_ST_SIGMA || mode == NL_ST_WINSOR_SIGMA) && !weighted && n_frames > 128 && n_frames <= 512 &&
-            npix < ((int64_t)1 << 27)) ? 1 : 0;
+    if (n_frames <= 128 || n_frames > 512 || npix >= ((int64_t)1 << 27)) return 0;
+    if (mode == NL_ST_MEDIAN) return 1;
+    return ((mode == NL_ST_SIGMA || mode == NL_ST_WINSOR_SIGMA) && !weighted) ? 1 : 0;
 }
 
 template <int LPP, bool WINSOR, bool WIDE>

@@ -419,3 +419,14 @@ def test_large_stacks_weighted_and_mad_on_the_exact_kernel(nl, oracle, mode, n):
     assert same_values(got, want), "%s n=%d: %s" % (MODES[mode], n, describe_mismatch(got, want))
     if mode >= 2:
         assert gc == wc
+
+
+@pytest.mark.parametrize("n", [129, 200, 256, 257, 300, 500, 512])
+def test_multi_lane_median_129_to_512_frames(nl, oracle, n):
+    # stack_median_ml_kernel: merged column across 2 / 4 lanes, whole-lane rank lookup; bit-exact
+    width, height = 67, 9
+    frames = make_frames(n, width, height, seed=1200 + n, nan_frac=0.02, ties=(n % 2 == 0))
+    frames[0, 5] = np.inf
+    frames[n - 1, 6] = -np.inf
+    got, _, want, _ = run_both(nl, oracle, 0, frames, width, height, None, 0, 0, exact=False)
+    assert same_values(got, want), "multi-lane median n=%d: %s" % (n, describe_mismatch(got, want))

@@ -44,8 +44,11 @@ __device__ float hoare_select(Col<S> a, int n, int k)
         int l = left - 1, r = right + 1;
         for (;;) {
             float al, ar;
-            do { l++; al = a.get(l); } while (!(al >= pivot));
-            do { r--; ar = a.get(r); } while (!(ar <= pivot));
+            // (the index guards never fire on NaN-free data; they keep a NaN -- only possible in
+            // MAD deviations of a pixel with an infinite median, where the reference itself dies
+            // with an index panic -- from sending the scan past the column forever)
+            do { l++; al = a.get(l); } while (!(al >= pivot) && l < right);
+            do { r--; ar = a.get(r); } while (!(ar <= pivot) && r > left);
             if (l >= r) break;
             a.set(l, ar);
             a.set(r, al);

@@ -109,6 +109,117 @@ __global__ __launch_bounds__(256) void stack_median_fast_kernel(StackArgs p, Fas
     }
 }
 
+// StackMADSigma (stack.go:536-605), register resident.  The clip bounds come from two
+// medians (of the samples, and of their absolute deviations from it), both order
+// independent, so the bounds, every clip decision and both counters are exact without
+// any guard; only the final mean is an order dependent fp32 sum (the reference adds the
+// survivors in the order two quickselects and the clip swaps left them), which this
+// kernel forms in frame order: <= summation-order rounding, like the sigma kernel.
+//   1. gather + sort            -> median (lookup)
+//   2. column := |x - median|   -> sort again -> MAD (lookup); the samples are gone
+//   3. second read of the pixel's frames (L2 / MALL resident), in frame order:
+//      count x < lo, x > hi, sum the rest
+// A pixel whose median is not finite (half of its samples infinite) has NaN deviations
+// (Inf - Inf); what the reference's quickselect makes of those depends on where they sit
+// (for some inputs it runs off the array and panics).  Such a pixel goes to the exact
+// kernel, which follows the reference step by step where that is defined.
+template <int NS>
+__global__ __launch_bounds__(256) void stack_mad_fast_kernel(StackArgs p, FastArgs q)
+{
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = pix < p.npix;
+    const int lane = threadIdx.x & 63;
+    const unsigned boff = (unsigned)(on ? pix : 0) * 4u;
+    int N = p.n_frames;
+    asm volatile("" : "+s"(N));
+    float v[NS];
+    const int n = gather_sorted<NS>(p.frames, p.stride, N, boff, v);
+    const int kk = n >> 1;                                   // qsort.go:70: k = (n>>1)+1, 1-based
+    const float upper = pick<0, NS>(v, kk);
+    const float lower = pick<0, NS>(v, kk > 0 ? kk - 1 : 0);
+    const float median = (n & 1) ? upper : 0.5f * (lower + upper);
+    const bool degenerate = n > 0 && !(__builtin_fabsf(median) < __builtin_inff());
+    const float msafe = degenerate ? 0.0f : median;
+    static_chunks<0, NS, 16>([&](auto K) NL_INL {
+        constexpr int k = decltype(K)::value;
+        v[k] = __builtin_fabsf(v[k] - msafe);                // stack.go:566-571 (pads stay +Inf)
+    });
+    sort_network<NS>(v);
+    const float dupper = pick<0, NS>(v, kk);
+    const float dlower = pick<0, NS>(v, kk > 0 ? kk - 1 : 0);
+    const float mad = (n & 1) ? dupper : 0.5f * (dlower + dupper);
+    const float sd = mad * 1.4826f;                          // stack.go:574
+    const float t_lo = p.sig_lo * sd, t_hi = p.sig_hi * sd;
+    const float lo = median - t_lo, hi = median + t_hi;
+
+    // second read, frame order: all loads first, into the column's registers (free again)
+    // (frame count and pitch re-read through opaque registers: otherwise the scalar offsets and
+    // descriptors of the first gather are kept alive across both sorts for re-use here)
+    int N2 = p.n_frames;
+    asm volatile("" : "+s"(N2));
+    int64_t frame_bytes = p.stride * (int64_t)sizeof(float);
+    asm volatile("" : "+s"(frame_bytes));
+    const int last = N2 - 1;
+    static_chunks<0, NS / 4, 4>([&](auto C) NL_INL {
+        constexpr int c0 = 4 * decltype(C)::value;
+        const int f0 = min(c0, last);
+        const char *gb = reinterpret_cast<const char *>(p.frames) + (int64_t)f0 * frame_bytes;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gb), 0, -1, 0x00020000);
+        static_range<0, 4>([&](auto U) NL_INL {
+            constexpr int k = c0 + decltype(U)::value;
+            const int soff = (min(k, last) - f0) * (int)frame_bytes;
+            v[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)boff, soff, 0));
+        });
+    });
+    // counts as floats (exact far beyond 128): integer sums would be re-associated into a tree,
+    // which keeps one lane mask per sample alive
+    float f_lo = 0.0f, f_hi = 0.0f, f_kept = 0.0f, sum = 0.0f;
+    static_chunks<0, NS, 4>([&](auto K) NL_INL {
+        constexpr int k = decltype(K)::value;
+        const float x = v[k];
+        const bool present = (k < N2) && (x == x);           // NaN = no data, positions past N unused
+        const bool below = present && x < lo;                // stack.go:583-592: low first
+        const bool above = present && !below && x > hi;
+        const bool keep = present && !below && !above;
+        f_lo += below ? 1.0f : 0.0f;
+        f_hi += above ? 1.0f : 0.0f;
+        f_kept += keep ? 1.0f : 0.0f;
+        sum += keep ? x : 0.0f;
+        // (pinned here: otherwise the four chains are sunk below all compares and every
+        // sample's lane masks are parked in SGPRs until then)
+        asm volatile("" : "+v"(f_lo), "+v"(f_hi), "+v"(f_kept), "+v"(sum));
+    });
+    int c_lo = (int)f_lo, c_hi = (int)f_hi;
+    float res = sum / f_kept;                                // no survivor: 0/0 = NaN, as the reference
+    if (n == 0) res = p.ref_loc;
+    const bool to_exact = on && degenerate;
+    if (on && !to_exact) p.out[pix] = res;
+    if (!on || to_exact || n == 0) { c_lo = 0; c_hi = 0; }
+    const unsigned long long em = __ballot(to_exact);
+    if (em) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(q.fb_count, (unsigned)__popcll(em));
+        base = __shfl(base, 0, 64);
+        const unsigned slot = base + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
+        if (to_exact && slot < q.fb_capacity) q.fb_list[slot] = (unsigned)pix;
+    }
+    __shared__ int s_lo[4], s_hi[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c_lo += __shfl_xor(c_lo, o, 64);
+        c_hi += __shfl_xor(c_hi, o, 64);
+    }
+    if (lane == 0) { s_lo[threadIdx.x >> 6] = c_lo; s_hi[threadIdx.x >> 6] = c_hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t_l = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3];
+        const int t_h = s_hi[0] + s_hi[1] + s_hi[2] + s_hi[3];
+        unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+        if (t_l) atomicAdd(slot + 0, (unsigned long long)t_l);
+        if (t_h) atomicAdd(slot + 1, (unsigned long long)t_h);
+    }
+}
+
 // ZONAL = true : grid covers the tile, lane = pixel blockIdx*256+thread;
 // ZONAL = false: grid-stride over q.in_list (pixels handed over by the zonal
 //                kernel), any number of missing / clipped samples.
@@ -526,6 +637,35 @@ hipError_t launch_stack_median_fast(const StackArgs &args, const FastArgs &fargs
     return hipGetLastError();
 }
 
+
+template <int NS>
+static void launch_mad(const StackArgs &args, const FastArgs &f, unsigned blocks, hipStream_t stream, const char **name)
+{
+    static const std::string nm = "stack_mad_fast_kernel<" + std::to_string(NS) + ">";
+    *name = nm.c_str();
+    hipLaunchKernelGGL(stack_mad_fast_kernel<NS>, dim3(blocks), dim3(256), 0, stream, args, f);
+}
+
+int mad_fast_supported(int mode, bool weighted, int n_frames)
+{
+    return (mode == NL_ST_MAD_SIGMA && !weighted && n_frames >= 1 && n_frames <= 128) ? 1 : 0;
+}
+
+hipError_t launch_stack_mad_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name)
+{
+    const unsigned blocks = (unsigned)((args.npix + 255) / 256);
+    const int n = args.n_frames;
+    if (n <= 8)        launch_mad<8>(args, fargs, blocks, stream, name);
+    else if (n <= 16)  launch_mad<16>(args, fargs, blocks, stream, name);
+    else if (n <= 32)  launch_mad<32>(args, fargs, blocks, stream, name);
+    else if (n <= 48)  launch_mad<48>(args, fargs, blocks, stream, name);
+    else if (n <= 64)  launch_mad<64>(args, fargs, blocks, stream, name);
+    else if (n <= 80)  launch_mad<80>(args, fargs, blocks, stream, name);
+    else if (n <= 96)  launch_mad<96>(args, fargs, blocks, stream, name);
+    else if (n <= 112) launch_mad<112>(args, fargs, blocks, stream, name);
+    else               launch_mad<128>(args, fargs, blocks, stream, name);
+    return hipGetLastError();
+}
 
 // smallest network size with a zonal instantiation
 constexpr int kZonalMinSize = 24;

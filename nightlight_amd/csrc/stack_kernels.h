@@ -58,6 +58,8 @@ int fast_supported(int mode, bool weighted, int n_frames);
 hipError_t launch_stack_median_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
                                     const char **name, hipEvent_t dominant_done);
 // dominant_done (optional) is recorded right after the first, dominant kernel
+int mad_fast_supported(int mode, bool weighted, int n_frames);
+hipError_t launch_stack_mad_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name);
 // after_dominant(user) is called between the launch of the dominant (zonal) kernel and
 // the generic pass, so the caller can start work that only depends on the former
 typedef void (*AfterDominant)(void *user);

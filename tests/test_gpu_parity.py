@@ -430,3 +430,20 @@ def test_multi_lane_median_129_to_512_frames(nl, oracle, n):
     frames[n - 1, 6] = -np.inf
     got, _, want, _ = run_both(nl, oracle, 0, frames, width, height, None, 0, 0, exact=False)
     assert same_values(got, want), "multi-lane median n=%d: %s" % (n, describe_mismatch(got, want))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 9, 16, 25, 33, 64, 65, 100, 128])
+def test_register_resident_mad_counts_exact_values_close(nl, oracle, n):
+    # default dispatch for MAD clipping (stack_mad_fast_kernel): the bounds come from two medians,
+    # so the counters are exact; the mean of the survivors is summed in frame order
+    width, height = 131, 17
+    frames = make_frames(n, width, height, seed=1400 + n, ties=(n % 4 == 0))
+    if n > 3:
+        frames[0, 11] = np.inf               # one infinite sample: finite median, handled in place
+        frames[:, 13] = 5.0                  # constant pixel: MAD 0, nothing clipped
+        # (an infinite MEDIAN is not tested against the oracle: Inf - Inf puts NaNs into the
+        # deviations and the reference's quickselect then indexes past the array and panics)
+    for sl, sh in ((2.75, 2.75), (0.5, 3.0)):
+        got, gc, want, wc = run_both(nl, oracle, 4, frames, width, height, None, sl, sh, exact=False)
+        assert gc == wc, "mad n=%d clip counters %r vs oracle %r" % (n, gc, wc)
+        assert close_values(got, want), "mad n=%d: %s" % (n, describe_mismatch(got, want))

@@ -495,6 +495,29 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
         h->last_has_counters = true;
         h->last_used_fast = true;
+    } else if (!h->force_exact && h->d_fb_list && nl::linfit_ml_supported(mode, a.n_frames, a.npix)) {
+        // 129..512 frames: 2 or 4 lanes per pixel, the sums chained through the lanes; bit-exact
+        nl::FastArgs f;
+        memset(&f, 0, sizeof f);
+        f.fb_list = h->d_fb_list;
+        f.fb_count = h->d_fb_count;
+        f.fb_capacity = (unsigned)h->npix;
+        NL_HIP(nl::launch_stack_linfit_ml(a, f, h->stream, &h->last_kernel));
+        NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
+        int lanes = 0;
+        size_t lds = 0;
+        if (nl::exact_plan(mode, weighted, a.n_frames, a.n_pad, kListLanes, &lanes, &lds) != 0)
+            return fail(NL_ERR_TOO_MANY_FRAMES,
+                        "%d frames do not fit the per-pixel LDS column (mode %d)", a.n_frames, mode);
+        nl::StackArgs e = a;
+        e.list = h->d_fb_list;
+        e.list_count = h->d_fb_count;
+        e.list_capacity = (unsigned)h->npix;
+        const char *exact_name = "";
+        NL_HIP(nl::launch_stack_exact(mode, weighted, e, lanes, kListGrid, lds, h->stream, &exact_name));
+        NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
+        h->last_has_counters = true;
+        h->last_used_fast = true;
     } else if (!h->force_exact && h->d_fb_list && nl::linfit_fast_supported(mode, a.n_frames)) {
         // register-resident linear fit: bit-exact (sums run in sorted order);
         // only pixels with an infinite sample are replayed by the LDS kernel

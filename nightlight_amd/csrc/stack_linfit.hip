@@ -15,7 +15,7 @@
 // One pixel per lane, samples in VGPRs, no LDS, no hand-over lists (a pixel
 // with a +-Inf sample is replayed by the LDS kernel: its pads are +Inf too).
 // MeanStdDev of xs = 0..m-1 depends on m only and comes from the host table.
-#include "fast_common.hpp"
+#include "fast_ml_common.hpp"
 
 namespace nl {
 
@@ -248,6 +248,220 @@ __global__ __launch_bounds__(256) void stack_linfit_fast_kernel(StackArgs p, Fas
         if (t_lo) atomicAdd(slot + 0, (unsigned long long)t_lo);
         if (t_hi) atomicAdd(slot + 1, (unsigned long long)t_hi);
     }
+}
+
+// ---- 129 .. 512 frames: 2 or 4 lanes per pixel ---------------------------------------
+// After ml_gather_sorted lane r of a pixel holds the sorted ranks [128r, 128r+128).  The
+// reference's sums run over the sorted samples in index order, i.e. lane 0's column, then
+// lane 1's, ...: a chain that crosses the lanes.  Every chained pass is therefore issued LPP
+// times; in round j the lanes start from the value lane j-1 finished with (broadcast inside
+// the quad) and only lane j's result is kept.  The index among the survivors at the start
+// of a lane, the reject flags and the counters do not depend on the chain and are formed in
+// parallel.  Same fp32 operations in the same order as the one-lane kernel: bit-exact.
+template <int LPP, int J>
+__device__ __forceinline__ float quad_from(float x)       // value of the pixel's lane J, in every lane
+{
+    if constexpr (LPP == 2) return dpp_f<J == 0 ? 0xA0 : 0xF5>(x);            // quad_perm [0,0,2,2] / [1,1,3,3]
+    else return dpp_f<J == 0 ? 0x00 : (J == 1 ? 0x55 : (J == 2 ? 0xAA : 0xFF))>(x);
+}
+
+template <int LPP>
+__global__ __launch_bounds__(256) void stack_linfit_ml_kernel(StackArgs p, FastArgs q)
+{
+    constexpr int NS = kMlNS, NW = NS / 32;
+    const int lane = threadIdx.x & 63;
+    const int role = threadIdx.x % LPP;
+    const int64_t pix = (int64_t)blockIdx.x * (blockDim.x / LPP) + threadIdx.x / LPP;
+    const bool on = pix < p.npix;
+    int N = p.n_frames;
+    asm volatile("" : "+s"(N));
+    float v[NS];
+    const int n = ml_gather_sorted<LPP, NS, false>(p.frames, p.stride, N, on, pix, role, v);
+    const int n_loc = min(max(n - role * NS, 0), NS);           // valid samples in this lane
+
+    unsigned live[NW];
+    static_range<0, NW>([&](auto W) NL_INL {
+        constexpr int w = decltype(W)::value;
+        const int c = min(max(n_loc - 32 * w, 0), 32);
+        live[w] = c >= 32 ? 0xFFFFFFFFu : ((1u << c) - 1u);
+    });
+    unsigned inf_loc = 0;
+    {
+        int nn = n_loc;
+        static_chunks<0, NS, 8>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            if constexpr ((k & 7) == 0) nn = opaque(nn);
+            const unsigned pad = (unsigned)((nn - 1 - k) >> 31);
+            const unsigned bits = (unsigned)__float_as_int(v[k]);
+            inf_loc |= (((bits & 0x7fffffffu) == 0x7f800000u) ? 1u : 0u) & ~pad;
+            v[k] = __int_as_float((int)(bits & ~pad));                       // pads -> +0.0f
+        });
+    }
+    const bool to_exact = quad_or<LPP>((int)inf_loc) != 0;
+
+    float res = p.ref_loc;
+    int c_lo = 0, c_hi = 0;
+    int m = n;
+    bool active = on && n > 0 && !to_exact;
+
+    while (__any(active)) {
+        const float fm = (float)m;
+        const int mt = (active && m >= 1) ? m : 1;
+        const float xm = p.xstat[2 * mt], xsd = p.xstat[2 * mt + 1];
+        // survivors in the lanes before this one = index among the survivors of this lane's first
+        int live_loc = 0;
+        static_range<0, NW>([&](auto W) NL_INL { live_loc += __popc(live[decltype(W)::value]); });
+        int before = 0;
+        {
+            const int l1 = dpp_i<kSwap1>(live_loc);
+            if constexpr (LPP == 2) {
+                before = (role & 1) ? l1 : 0;
+            } else {
+                const int pair = live_loc + l1;                       // lanes {0,1} or {2,3}
+                const int other = dpp_i<kSwap2>(pair);
+                before = ((role & 1) ? l1 : 0) + ((role & 2) ? other : 0);
+            }
+        }
+        const float fi0 = (float)before;
+#define NL_LF(k) ((float)((live[(k) >> 5] >> ((k) & 31)) & 1u))
+        // ---- sum of the ys (stats.go:248-251), chained through the lanes ----
+        float s = 0.0f;
+        static_range<0, LPP>([&](auto J) NL_INL {
+            constexpr int j = decltype(J)::value;
+            float t = s;
+            static_chunks<0, NS, 16>([&](auto K) NL_INL {
+                constexpr int k = decltype(K)::value;
+                t = __fadd_rn(t, __fmul_rn(v[k], NL_LF(k)));
+            });
+            s = quad_from<LPP, j>(t);
+            forget_words<NW>(live);
+        });
+        const float ym = s / fm;
+        // ---- variance and correlation sums (stats.go:254-257, 573-579) ----
+        float vs = 0.0f, corr = 0.0f;
+        static_range<0, LPP>([&](auto J) NL_INL {
+            constexpr int j = decltype(J)::value;
+            float tv = vs, tc = corr, fi = fi0;
+            const float ym2 = opaque_f(ym);
+            static_chunks<0, NS, 16>([&](auto K) NL_INL {
+                constexpr int k = decltype(K)::value;
+                const float lf = NL_LF(k);
+                const float dy = __fsub_rn(v[k], ym2);
+                const float dd = __fmul_rn(dy, dy);
+                tv = __fadd_rn(tv, __fmul_rn(dd, lf));
+                const float dx = __fsub_rn(fi, xm);
+                const float t = __fmul_rn(dx, dy);
+                tc = __fadd_rn(tc, __fmul_rn(t, lf));
+                fi += lf;
+            });
+            vs = quad_from<LPP, j>(tv);
+            corr = quad_from<LPP, j>(tc);
+            forget_words<NW>(live);
+        });
+        const float ysd = sqrt_go(vs / fm);
+        float den = __fmul_rn(xsd, ysd);
+        den = __fmul_rn(den, __fadd_rn(fm, 1.0f));
+        corr = corr / den;
+        float slope = __fmul_rn(corr, ysd);
+        slope = slope / xsd;
+        float icpt = __fsub_rn(ym, __fmul_rn(slope, xm));
+        // ---- mean absolute deviation from the fit (stack.go:879-886) ----
+        float sg = 0.0f;
+        static_range<0, LPP>([&](auto J) NL_INL {
+            constexpr int j = decltype(J)::value;
+            float t = sg, fi = fi0;
+            const float sl2 = opaque_f(slope);
+            static_chunks<0, NS, 16>([&](auto K) NL_INL {
+                constexpr int k = decltype(K)::value;
+                const float lf = NL_LF(k);
+                const float lin = __fadd_rn(__fmul_rn(fi, sl2), icpt);
+                const float diff = __fsub_rn(v[k], lin);
+                t = __fadd_rn(t, __fmul_rn(fabsf(diff), lf));
+                fi += lf;
+            });
+            sg = quad_from<LPP, j>(t);
+            forget_words<NW>(live);
+        });
+        sg = sg / fm;
+        // ---- reject (stack.go:890-904): no chain, every lane does its own ranks ----
+        float lb = __fmul_rn(p.sig_lo, sg), hb = __fmul_rn(p.sig_hi, sg);
+        const bool bad = !(slope == slope) || !(icpt == icpt) || !(lb == lb) || !(hb == hb);
+        if (bad) { slope = 0.0f; icpt = 0.0f; lb = __builtin_inff(); hb = __builtin_inff(); }
+        unsigned lo_n = 0, hi_n = 0;
+        unsigned nlive[NW];
+        static_range<0, NW>([&](auto W) NL_INL { nlive[decltype(W)::value] = live[decltype(W)::value]; });
+        float fi = fi0;
+        slope = opaque_f(slope);
+        static_chunks<0, NS, 16>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            const unsigned lbit = (live[k >> 5] >> (k & 31)) & 1u;
+            const float g = v[k];
+            const float lin = __fadd_rn(__fmul_rn(fi, slope), icpt);
+            const unsigned low = sign_bit(__fsub_rn(lb, __fsub_rn(lin, g))) & lbit;
+            const unsigned high = sign_bit(__fsub_rn(hb, __fsub_rn(g, lin))) & lbit & ~low;
+            lo_n = opaque_u(lo_n + low);
+            hi_n = opaque_u(hi_n + high);
+            nlive[k >> 5] = opaque_u(nlive[k >> 5] & ~((low | high) << (k & 31)));
+            fi += (float)lbit;
+        });
+#undef NL_LF
+        const int lo_all = quad_sum<LPP>((int)lo_n), hi_all = quad_sum<LPP>((int)hi_n);
+        if (active) {
+            c_lo += lo_all;
+            c_hi += hi_all;
+            const int left = lo_all + hi_all;
+            res = ym;                                       // stack.go:911
+            if (left == 0 || m < 3) active = false;
+            m -= left;
+            static_range<0, NW>([&](auto W) NL_INL { live[decltype(W)::value] = nlive[decltype(W)::value]; });
+        }
+    }
+
+    const bool rep = on && role == 0;
+    if (rep && !to_exact) p.out[pix] = res;
+    if (!rep || to_exact) { c_lo = 0; c_hi = 0; }
+    const unsigned long long em = __ballot(rep && to_exact);
+    if (em) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(q.fb_count, (unsigned)__popcll(em));
+        base = __shfl(base, 0, 64);
+        const unsigned slot = base + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
+        if (rep && to_exact && slot < q.fb_capacity) q.fb_list[slot] = (unsigned)pix;
+    }
+    __shared__ int s_lo[4], s_hi[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c_lo += __shfl_xor(c_lo, o, 64);
+        c_hi += __shfl_xor(c_hi, o, 64);
+    }
+    if (lane == 0) { s_lo[threadIdx.x >> 6] = c_lo; s_hi[threadIdx.x >> 6] = c_hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t_lo = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3];
+        const int t_hi = s_hi[0] + s_hi[1] + s_hi[2] + s_hi[3];
+        unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+        if (t_lo) atomicAdd(slot + 0, (unsigned long long)t_lo);
+        if (t_hi) atomicAdd(slot + 1, (unsigned long long)t_hi);
+    }
+}
+
+int linfit_ml_supported(int mode, int n_frames, int64_t npix)
+{
+    return (mode == NL_ST_LINEAR_FIT && n_frames > 128 && n_frames <= 512 && npix < ((int64_t)1 << 27)) ? 1 : 0;
+}
+
+hipError_t launch_stack_linfit_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name)
+{
+    if (args.n_frames <= 2 * kMlNS) {
+        *name = "stack_linfit_ml_kernel<2>";
+        hipLaunchKernelGGL(stack_linfit_ml_kernel<2>, dim3((unsigned)((args.npix + 127) / 128)), dim3(256), 0, stream,
+                           args, fargs);
+    } else {
+        *name = "stack_linfit_ml_kernel<4>";
+        hipLaunchKernelGGL(stack_linfit_ml_kernel<4>, dim3((unsigned)((args.npix + 63) / 64)), dim3(256), 0, stream,
+                           args, fargs);
+    }
+    return hipGetLastError();
 }
 
 int linfit_fast_supported(int mode, int n_frames)

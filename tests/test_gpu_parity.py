@@ -447,3 +447,17 @@ def test_register_resident_mad_counts_exact_values_close(nl, oracle, n):
         got, gc, want, wc = run_both(nl, oracle, 4, frames, width, height, None, sl, sh, exact=False)
         assert gc == wc, "mad n=%d clip counters %r vs oracle %r" % (n, gc, wc)
         assert close_values(got, want), "mad n=%d: %s" % (n, describe_mismatch(got, want))
+
+
+@pytest.mark.parametrize("n", [129, 160, 200, 256, 257, 300, 384, 512])
+def test_multi_lane_linear_fit_129_to_512_frames(nl, oracle, n):
+    # stack_linfit_ml_kernel: the sequential sums are chained through the 2 / 4 lanes of a pixel
+    # in sorted order -> bit-exact, counters included
+    width, height = 67, 5
+    frames = make_frames(n, width, height, seed=1600 + n, nan_frac=0.01, ties=(n % 3 == 0))
+    frames[1, 3] = np.inf                # infinite sample -> exact kernel
+    frames[:, 17] = 1234.5               # zero variance: NaN slope, no rejection
+    for sl, sh in ((2.75, 2.75), (1.0, 3.0)):
+        got, gc, want, wc = run_both(nl, oracle, 5, frames, width, height, None, sl, sh, exact=False)
+        assert same_values(got, want), "multi-lane linear fit n=%d: %s" % (n, describe_mismatch(got, want))
+        assert gc == wc, "multi-lane linear fit n=%d clip counters %r vs oracle %r" % (n, gc, wc)

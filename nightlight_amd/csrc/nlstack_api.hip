@@ -403,6 +403,35 @@ int nl_weights_from_scalars(int weighting, const float *per_frame, int n_frames,
     return fail(NL_ERR_INVALID_WEIGHTING, "Invalid weighting mode %d\n", weighting);
 }
 
+// Linear-fit cascade buffers (stack_linfit.hip): two pixel lists and two state arrays with
+// lanes_per_pixel liveness masks (16 B) per pixel, allocated on first use.  Without them
+// (allocation failure) the kernels run as a single stage.
+static const nl::LinfitCascade *linfit_cascade(nl_stack_t *h, int lanes_per_pixel, nl::LinfitCascade *out)
+{
+    if (!h->lf_tried) {
+        h->lf_tried = true;
+        const size_t np = (size_t)h->npix;
+        bool ok = hipMalloc(&h->d_lf_count, sizeof(unsigned) * nl::kLinfitStages) == hipSuccess;
+        for (int i = 0; i < 2 && ok; i++)
+            ok = hipMalloc(&h->d_lf_list[i], sizeof(unsigned) * np) == hipSuccess &&
+                 hipMalloc(&h->d_lf_state[i], sizeof(uint4) * np * (size_t)lanes_per_pixel) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            for (int i = 0; i < 2; i++) {
+                if (h->d_lf_list[i]) { (void)hipFree(h->d_lf_list[i]); h->d_lf_list[i] = nullptr; }
+                if (h->d_lf_state[i]) { (void)hipFree(h->d_lf_state[i]); h->d_lf_state[i] = nullptr; }
+            }
+            if (h->d_lf_count) { (void)hipFree(h->d_lf_count); h->d_lf_count = nullptr; }
+        }
+    }
+    if (!(h->d_lf_count && h->d_lf_state[1])) return nullptr;
+    out->list[0] = h->d_lf_list[0]; out->list[1] = h->d_lf_list[1];
+    out->state[0] = h->d_lf_state[0]; out->state[1] = h->d_lf_state[1];
+    out->count = h->d_lf_count;
+    out->capacity = (unsigned)h->npix;
+    return out;
+}
+
 static int auto_select_mode(int l)   // stack.go:45-55
 {
     if (l >= 25) return NL_ST_LINEAR_FIT;
@@ -502,8 +531,10 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         f.fb_list = h->d_fb_list;
         f.fb_count = h->d_fb_count;
         f.fb_capacity = (unsigned)h->npix;
-        NL_HIP(nl::launch_stack_linfit_ml(a, f, h->stream, &h->last_kernel));
-        NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
+        nl::LinfitCascade cascade;
+        const nl::LinfitCascade *cas = linfit_cascade(h, a.n_frames <= 256 ? 2 : 4, &cascade);
+        if (cas) NL_HIP(hipMemsetAsync(h->d_lf_count, 0, sizeof(unsigned) * nl::kLinfitStages, h->stream));
+        NL_HIP(nl::launch_stack_linfit_ml(a, f, cas, h->stream, &h->last_kernel, h->ev_dom1));
         int lanes = 0;
         size_t lds = 0;
         if (nl::exact_plan(mode, weighted, a.n_frames, a.n_pad, kListLanes, &lanes, &lds) != 0)
@@ -526,33 +557,9 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         f.fb_list = h->d_fb_list;
         f.fb_count = h->d_fb_count;
         f.fb_capacity = (unsigned)h->npix;
-        // cascade buffers (20 B per pixel, twice): without them the kernel runs as one stage
-        if (!h->lf_tried) {
-            h->lf_tried = true;
-            const size_t np = (size_t)h->npix;
-            bool ok = hipMalloc(&h->d_lf_count, sizeof(unsigned) * nl::kLinfitStages) == hipSuccess;
-            for (int i = 0; i < 2 && ok; i++)
-                ok = hipMalloc(&h->d_lf_list[i], sizeof(unsigned) * np) == hipSuccess &&
-                     hipMalloc(&h->d_lf_state[i], sizeof(uint4) * np) == hipSuccess;
-            if (!ok) {
-                (void)hipGetLastError();
-                for (int i = 0; i < 2; i++) {
-                    if (h->d_lf_list[i]) { (void)hipFree(h->d_lf_list[i]); h->d_lf_list[i] = nullptr; }
-                    if (h->d_lf_state[i]) { (void)hipFree(h->d_lf_state[i]); h->d_lf_state[i] = nullptr; }
-                }
-                if (h->d_lf_count) { (void)hipFree(h->d_lf_count); h->d_lf_count = nullptr; }
-            }
-        }
         nl::LinfitCascade cascade;
-        const nl::LinfitCascade *cas = nullptr;
-        if (h->d_lf_count && h->d_lf_state[1]) {
-            cascade.list[0] = h->d_lf_list[0]; cascade.list[1] = h->d_lf_list[1];
-            cascade.state[0] = h->d_lf_state[0]; cascade.state[1] = h->d_lf_state[1];
-            cascade.count = h->d_lf_count;
-            cascade.capacity = (unsigned)h->npix;
-            NL_HIP(hipMemsetAsync(h->d_lf_count, 0, sizeof(unsigned) * nl::kLinfitStages, h->stream));
-            cas = &cascade;
-        }
+        const nl::LinfitCascade *cas = linfit_cascade(h, 1, &cascade);
+        if (cas) NL_HIP(hipMemsetAsync(h->d_lf_count, 0, sizeof(unsigned) * nl::kLinfitStages, h->stream));
         NL_HIP(nl::launch_stack_linfit_fast(a, f, cas, h->stream, &h->last_kernel, h->ev_dom1));
         int lanes = 0;
         size_t lds = 0;

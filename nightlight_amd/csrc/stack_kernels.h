@@ -91,9 +91,11 @@ struct LinfitCascade {
 constexpr int kLinfitStages = 4;
 int linfit_fast_supported(int mode, int n_frames);
 int linfit_ml_supported(int mode, int n_frames, int64_t npix);
-hipError_t launch_stack_linfit_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name);
+
 hipError_t launch_stack_linfit_fast(const StackArgs &args, const FastArgs &fargs, const LinfitCascade *cascade,
                                     hipStream_t stream, const char **name, hipEvent_t dominant_done);
+hipError_t launch_stack_linfit_ml(const StackArgs &args, const FastArgs &fargs, const LinfitCascade *cascade,
+                                  hipStream_t stream, const char **name, hipEvent_t dominant_done);
 
 // ---- stack_mean.hip ----
 hipError_t launch_stack_mean(bool weighted, const StackArgs &args, hipStream_t stream,

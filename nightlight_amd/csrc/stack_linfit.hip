@@ -265,14 +265,21 @@ __device__ __forceinline__ float quad_from(float x)       // value of the pixel'
     else return dpp_f<J == 0 ? 0x00 : (J == 1 ? 0x55 : (J == 2 ? 0xAA : 0xFF))>(x);
 }
 
-template <int LPP>
-__global__ __launch_bounds__(256) void stack_linfit_ml_kernel(StackArgs p, FastArgs q)
+template <int LPP, bool CONT>
+__global__ __launch_bounds__(256) void stack_linfit_ml_kernel(StackArgs p, FastArgs q, LinfitStage g)
 {
     constexpr int NS = kMlNS, NW = NS / 32;
     const int lane = threadIdx.x & 63;
     const int role = threadIdx.x % LPP;
-    const int64_t pix = (int64_t)blockIdx.x * (blockDim.x / LPP) + threadIdx.x / LPP;
-    const bool on = pix < p.npix;
+    int c_lo = 0, c_hi = 0;
+    const int64_t limit = CONT ? (int64_t)min(*g.in_count, g.in_capacity) : p.npix;
+    const int64_t per_wg = blockDim.x / LPP;
+    const int64_t sweep = CONT ? (int64_t)gridDim.x * per_wg : limit;
+  for (int64_t wg_item = (int64_t)blockIdx.x * per_wg; wg_item < limit; wg_item += sweep) {
+    const int64_t item = wg_item + threadIdx.x / LPP;
+    const bool on = item < limit;
+    int64_t pix = item;
+    if (CONT) pix = on ? (int64_t)g.in_list[item] : 0;
     int N = p.n_frames;
     asm volatile("" : "+s"(N));
     float v[NS];
@@ -285,6 +292,12 @@ __global__ __launch_bounds__(256) void stack_linfit_ml_kernel(StackArgs p, FastA
         const int c = min(max(n_loc - 32 * w, 0), 32);
         live[w] = c >= 32 ? 0xFFFFFFFFu : ((1u << c) - 1u);
     });
+    int m_saved = n;
+    if constexpr (CONT) {               // liveness masks of this lane's ranks, saved by the previous stage
+        const uint4 st = g.in_state[(on ? item : 0) * LPP + role];
+        live[0] = st.x; live[1] = st.y; live[2] = st.z; live[3] = st.w;
+        m_saved = quad_sum<LPP>((int)(__popc(st.x) + __popc(st.y) + __popc(st.z) + __popc(st.w)));
+    }
     unsigned inf_loc = 0;
     {
         int nn = n_loc;
@@ -300,11 +313,13 @@ __global__ __launch_bounds__(256) void stack_linfit_ml_kernel(StackArgs p, FastA
     const bool to_exact = quad_or<LPP>((int)inf_loc) != 0;
 
     float res = p.ref_loc;
-    int c_lo = 0, c_hi = 0;
-    int m = n;
+    int p_lo = 0, p_hi = 0;
+    int m = m_saved;
     bool active = on && n > 0 && !to_exact;
+    int iters = 0;
 
-    while (__any(active)) {
+    while (__any(active) && (g.max_iters == 0 || iters < g.max_iters)) {
+        iters++;
         const float fm = (float)m;
         const int mt = (active && m >= 1) ? m : 1;
         const float xm = p.xstat[2 * mt], xsd = p.xstat[2 * mt + 1];
@@ -407,8 +422,8 @@ __global__ __launch_bounds__(256) void stack_linfit_ml_kernel(StackArgs p, FastA
 #undef NL_LF
         const int lo_all = quad_sum<LPP>((int)lo_n), hi_all = quad_sum<LPP>((int)hi_n);
         if (active) {
-            c_lo += lo_all;
-            c_hi += hi_all;
+            p_lo += lo_all;
+            p_hi += hi_all;
             const int left = lo_all + hi_all;
             res = ym;                                       // stack.go:911
             if (left == 0 || m < 3) active = false;
@@ -418,8 +433,21 @@ __global__ __launch_bounds__(256) void stack_linfit_ml_kernel(StackArgs p, FastA
     }
 
     const bool rep = on && role == 0;
-    if (rep && !to_exact) p.out[pix] = res;
-    if (!rep || to_exact) { c_lo = 0; c_hi = 0; }
+    const bool more = active;                      // not done within this stage's quota (same in all lanes of the pixel)
+    if (rep && !to_exact && !more) p.out[pix] = res;
+    if (rep && !to_exact) { c_lo += p_lo; c_hi += p_hi; }
+    const unsigned long long mm = __ballot(rep && more);
+    if (__any(more)) {
+        unsigned base = 0;
+        if (lane == 0 && mm) base = atomicAdd(g.out_count, (unsigned)__popcll(mm));
+        base = __shfl(base, 0, 64);
+        int slot = (int)(base + (unsigned)__popcll(mm & ((1ull << lane) - 1ull)));     // valid in the pixel's lane 0
+        slot = __float_as_int(quad_from<LPP, 0>(__int_as_float(slot)));
+        if (more && (unsigned)slot < g.out_capacity) {
+            if (role == 0) g.out_list[slot] = (unsigned)pix;
+            g.out_state[(int64_t)slot * LPP + role] = make_uint4(live[0], live[1], live[2], live[3]);
+        }
+    }
     const unsigned long long em = __ballot(rep && to_exact);
     if (em) {
         unsigned base = 0;
@@ -428,6 +456,8 @@ __global__ __launch_bounds__(256) void stack_linfit_ml_kernel(StackArgs p, FastA
         const unsigned slot = base + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
         if (rep && to_exact && slot < q.fb_capacity) q.fb_list[slot] = (unsigned)pix;
     }
+  }
+
     __shared__ int s_lo[4], s_hi[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -450,16 +480,49 @@ int linfit_ml_supported(int mode, int n_frames, int64_t npix)
     return (mode == NL_ST_LINEAR_FIT && n_frames > 128 && n_frames <= 512 && npix < ((int64_t)1 << 27)) ? 1 : 0;
 }
 
-hipError_t launch_stack_linfit_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name)
+template <int LPP>
+static void launch_lf_ml(const StackArgs &args, const FastArgs &f, const LinfitCascade *c, hipStream_t stream,
+                         hipEvent_t dominant_done)
+{
+    const unsigned per_wg = 256 / LPP;
+    const unsigned blocks = (unsigned)((args.npix + per_wg - 1) / per_wg);
+    LinfitStage g = {};
+    if (!c) {
+        hipLaunchKernelGGL((stack_linfit_ml_kernel<LPP, false>), dim3(blocks), dim3(256), 0, stream, args, f, g);
+        if (dominant_done) (void)hipEventRecord(dominant_done, stream);
+        return;
+    }
+    static const int quota[kLinfitStages] = {6, 6, 8, 0};        // as the one-lane kernel
+    for (int s = 0; s < kLinfitStages; s++) {
+        g.max_iters = quota[s];
+        g.in_list = s ? c->list[(s - 1) & 1] : nullptr;
+        g.in_state = s ? c->state[(s - 1) & 1] : nullptr;
+        g.in_count = s ? c->count + (s - 1) : nullptr;
+        g.in_capacity = c->capacity;
+        g.out_list = c->list[s & 1];
+        g.out_state = c->state[s & 1];
+        g.out_count = c->count + s;
+        g.out_capacity = c->capacity;
+        if (s == 0) {
+            hipLaunchKernelGGL((stack_linfit_ml_kernel<LPP, false>), dim3(blocks), dim3(256), 0, stream, args, f, g);
+            if (dominant_done) (void)hipEventRecord(dominant_done, stream);
+        } else {
+            const unsigned gblocks = blocks < 16384u ? blocks : 16384u;
+            hipLaunchKernelGGL((stack_linfit_ml_kernel<LPP, true>), dim3(gblocks), dim3(256), 0, stream, args, f, g);
+        }
+    }
+}
+
+// cascade->state must hold LPP entries per listed pixel (2 up to 256 frames, else 4)
+hipError_t launch_stack_linfit_ml(const StackArgs &args, const FastArgs &fargs, const LinfitCascade *cascade,
+                                  hipStream_t stream, const char **name, hipEvent_t dominant_done)
 {
     if (args.n_frames <= 2 * kMlNS) {
-        *name = "stack_linfit_ml_kernel<2>";
-        hipLaunchKernelGGL(stack_linfit_ml_kernel<2>, dim3((unsigned)((args.npix + 127) / 128)), dim3(256), 0, stream,
-                           args, fargs);
+        *name = "stack_linfit_ml_kernel<2, false>";
+        launch_lf_ml<2>(args, fargs, cascade, stream, dominant_done);
     } else {
-        *name = "stack_linfit_ml_kernel<4>";
-        hipLaunchKernelGGL(stack_linfit_ml_kernel<4>, dim3((unsigned)((args.npix + 63) / 64)), dim3(256), 0, stream,
-                           args, fargs);
+        *name = "stack_linfit_ml_kernel<4, false>";
+        launch_lf_ml<4>(args, fargs, cascade, stream, dominant_done);
     }
     return hipGetLastError();
 }

@@ -55,7 +55,8 @@ struct LinfitStage {
 };
 
 template <int NS, bool CONT>
-__global__ __launch_bounds__(256) void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS > 96 ? 3 : 1, 8)))
+void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
 {
     constexpr int NW = (NS + 31) / 32;          // liveness words per pixel
     const int lane = threadIdx.x & 63;
@@ -266,7 +267,8 @@ __device__ __forceinline__ float quad_from(float x)       // value of the pixel'
 }
 
 template <int LPP, bool CONT>
-__global__ __launch_bounds__(256) void stack_linfit_ml_kernel(StackArgs p, FastArgs q, LinfitStage g)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8)))
+void stack_linfit_ml_kernel(StackArgs p, FastArgs q, LinfitStage g)
 {
     constexpr int NS = kMlNS, NW = NS / 32;
     const int lane = threadIdx.x & 63;

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libnlstack.so")
+# NLSTACK_LIB: another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("NLSTACK_LIB") or os.path.join(_PKG, "libnlstack.so")
 
 ST_MEDIAN, ST_MEAN, ST_SIGMA, ST_WINSOR_SIGMA, ST_MAD_SIGMA, ST_LINEAR_FIT, ST_AUTO = range(7)
 WEIGHT_NONE, WEIGHT_EXPOSURE, WEIGHT_INVERSE_NOISE, WEIGHT_INVERSE_HFR = range(4)

@@ -636,11 +636,12 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
         h->last_has_counters = true;
         h->last_used_fast = true;
-    } else if ((h->exact_flavour == 2 || (!h->force_exact && weighted)) &&
+    } else if ((h->exact_flavour == 2 || (!h->force_exact && (weighted || a.n_frames > 512))) &&
                nl::coop_supported(mode, weighted, a.n_frames)) {
         // the wave-per-pixel exact replay over the whole tile: the default for weighted sigma /
         // winsorized clipping (their result depends on the reference's permutation, so there is
-        // no register-resident shortcut) and, with nl_stack_set_exact(h, 2), a verification path
+        // no register-resident shortcut) and beyond 512 frames; with nl_stack_set_exact(h, 2) a
+        // verification path
         h->last_used_fast = false;
         const int64_t g = a.npix < 65536 ? a.npix : 65536;
         NL_HIP(nl::launch_stack_sigma_coop(mode, a, (int)g, h->stream, &h->last_kernel));

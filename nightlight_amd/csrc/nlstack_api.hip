@@ -644,10 +644,11 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         // verification path
         h->last_used_fast = false;
         const int64_t g = a.npix < 65536 ? a.npix : 65536;
-        NL_HIP(nl::launch_stack_sigma_coop(mode, a, (int)g, h->stream, &h->last_kernel));
+        if (mode == NL_ST_MEDIAN) NL_HIP(nl::launch_stack_median_coop(a, (int)g, h->stream, &h->last_kernel));
+        else                      NL_HIP(nl::launch_stack_sigma_coop(mode, a, (int)g, h->stream, &h->last_kernel));
         NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
         NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
-        h->last_has_counters = true;
+        h->last_has_counters = (mode != NL_ST_MEDIAN);
     } else {
         h->last_used_fast = false;
         int lanes = 0;

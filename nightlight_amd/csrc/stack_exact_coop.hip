@@ -289,6 +289,41 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
     }
 }
 
+// StackMedian (stack.go:274-303) beyond the register kernels' 512 frames: gather and the
+// same wave-wide quickselect, nothing else.
+__global__ __launch_bounds__(64) void stack_median_coop_kernel(StackArgs p)
+{
+    extern __shared__ float a[];
+    int *lpos = reinterpret_cast<int *>(a + p.n_frames);
+    int *rfwd = lpos + p.n_frames;
+    const int lane = threadIdx.x;
+    const int N = p.n_frames;
+    for (int64_t pix = blockIdx.x; pix < p.npix; pix += gridDim.x) {
+        const float *fr = p.frames + pix;
+        lds_fence();
+        int n = 0;
+        for (int base = 0; base < N; base += 64) {
+            const int k = base + lane;
+            const float x = k < N ? fr[(int64_t)k * p.stride] : __builtin_nanf("");
+            const bool valid = x == x;
+            const unsigned long long m = __ballot(valid);
+            if (valid) a[n + __popcll(m & ((1ull << lane) - 1ull))] = x;
+            n += __popcll(m);
+        }
+        lds_fence();
+        const float res = n > 0 ? coop_select_median(a, lpos, rfwd, n) : p.ref_loc;
+        if (lane == 0) p.out[pix] = res;
+    }
+}
+
+hipError_t launch_stack_median_coop(const StackArgs &args, int grid, hipStream_t stream, const char **name)
+{
+    *name = "stack_median_coop_kernel";
+    hipLaunchKernelGGL(stack_median_coop_kernel, dim3(grid), dim3(64), (size_t)args.n_frames * 3 * sizeof(float), stream,
+                       args);
+    return hipGetLastError();
+}
+
 static size_t coop_columns(int mode, bool weighted)
 {
     return (mode == NL_ST_WINSOR_SIGMA ? 2 : 1) + (weighted ? 1 : 0) + 2;      // samples (+copy) (+weights) + 2 scratch
@@ -296,6 +331,7 @@ static size_t coop_columns(int mode, bool weighted)
 
 int coop_supported(int mode, bool weighted, int n_frames)
 {
+    if (mode == NL_ST_MEDIAN) return (size_t)n_frames * 3 * sizeof(float) <= 64 * 1024 ? 1 : 0;
     if (mode != NL_ST_SIGMA && mode != NL_ST_WINSOR_SIGMA) return 0;
     return (size_t)n_frames * coop_columns(mode, weighted) * sizeof(float) <= 64 * 1024 ? 1 : 0;
 }

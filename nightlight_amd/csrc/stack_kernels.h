@@ -76,6 +76,7 @@ hipError_t launch_stack_sigma_ml(const StackArgs &args, const FastArgs &fargs, h
 
 // ---- stack_exact_coop.hip (bit-exact sigma replay, one wave per pixel) ----
 int coop_supported(int mode, bool weighted, int n_frames);
+hipError_t launch_stack_median_coop(const StackArgs &args, int grid, hipStream_t stream, const char **name);
 hipError_t launch_stack_sigma_coop(int mode, const StackArgs &args, int grid, hipStream_t stream, const char **name);
 
 // ---- stack_linfit.hip (register-resident linear fit, bit-exact) ----

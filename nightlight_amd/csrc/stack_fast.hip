@@ -369,8 +369,9 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
             const float var = fmaxf(aa - bb, 0.0f);
 
             // ---- bracket the reference's stddev ----
-            // ours: every term of aa and bb carries <= ~(NS/4+16) roundings
-            const float err_o = ((float)(NS / 4 + 24)) * kU * (aa + bb);
+            // ours: aa carries <= NS/4+8 roundings per term; bb = delta^2 with delta off by
+            // <= (NS/4+7) u mean|e|, and 2|delta| mean|e| <= aa + bb: together <= (NS/2+17) u (aa+bb)
+            const float err_o = ((float)(NS / 2 + 24)) * kU * (aa + bb);
             // reference: relative gamma_(n+3) on its variance, its mean off by <= e_m
             const float eps_r = 1.02f * (fcnt + 8.0f) * kU;
             const float e_m = 1.02f * (fcnt + 2.0f) * kU * amax;
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                     const float wa = ((q0 + q1) + (q2 + q3)) * inv_cnt;      // covered by werr
                     const float wb = wd * wd;
                     wvar = fmaxf(wa - wb, 0.0f);
-                    werr = ((float)(NS / 4 + 34)) * kU * (wa + wb);
+                    werr = ((float)(NS / 2 + 34)) * kU * (wa + wb);
                     };
                     float var_t, err_t, var_l, err_l;
                     clamped_variance(wi.Lp, wi.Hm, var_t, err_t);

@@ -174,8 +174,8 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
             const float var = fmaxf(aa - bb, 0.0f);
 
             // ---- bracket the reference's stddev ----
-            // ours: every term carries <= NS/4 + log-depth quad adds + margin roundings
-            const float err_o = ((float)(NS / 4 + 32)) * kU * (aa + bb);
+            // ours: see stack_fast.hip (NS/2 + 17), plus the log-depth quad adds and a margin
+            const float err_o = ((float)(NS / 2 + 40)) * kU * (aa + bb);
             const float eps_r = 1.02f * (fcnt + 8.0f) * kU;
             const float e_m = 1.02f * (fcnt + 2.0f) * kU * amax;
             const float v_up = var + err_o;
@@ -255,7 +255,7 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
                         const float wa = quad_sum<LPP>((q0 + q1) + (q2 + q3)) * inv_cnt;
                         const float wb = wd * wd;
                         wvar = fmaxf(wa - wb, 0.0f);
-                        werr = ((float)(NS / 4 + 40)) * kU * (wa + wb);
+                        werr = ((float)(NS / 2 + 48)) * kU * (wa + wb);
                     };
                     float var_t, err_t, var_l, err_l;
                     clamped_variance(wi.Lp, wi.Hm, var_t, err_t);

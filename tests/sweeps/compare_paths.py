@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Developer utility (GPU box): run one synthetic stack through the default
+"""(Lives under tests/ because it uses the CPU oracle, which only tests, smoke() and the
+cpu_baseline leg of bench.py may touch.)
+Developer utility (GPU box): run one synthetic stack through the default
 dispatch, the forced bit-exact kernels and (optionally, on a row strip) the
 CPU oracle, and report where they differ.  Not part of the product path."""
 import argparse
@@ -9,7 +11,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nightlight_amd import StackHandle  # noqa: E402
 
 

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Large-sample parity sweep (run on the GPU box): several synthetic seeds and frame counts,
+"""(Lives under tests/ because it uses the CPU oracle, which only tests, smoke() and the
+cpu_baseline leg of bench.py may touch.)
+Large-sample parity sweep (run on the GPU box): several synthetic seeds and frame counts,
 the default dispatch through the C ABI against the CPU oracle on every pixel.  Clip counters
 must be identical; values bit-exact for the exact kernels, within 1e-5 for the register
 kernels.  Rare-event coverage (decisions with probabilities around 1e-7 per sample)."""
@@ -9,7 +11,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nightlight_amd.stack import StackHandle
 from oracle import oracle
 

@@ -142,6 +142,28 @@ __device__ __forceinline__ float pick_rank(const float (&v)[NS], int g, int role
 }
 
 // ZONAL / generic exactly as in stack_fast.hip; LPP lanes per pixel.
+// Sort every lane's column and merge the LPP runs of a pixel: afterwards lane r holds the global
+// ranks [r*NS, r*NS+NS).  ENDS_ONLY: the last merge orders only the KEEP lowest / highest ranks
+// of every lane (see half_clean_ends).
+template <int LPP, int NS, bool ENDS_ONLY>
+__device__ __forceinline__ void ml_sort_merge(float (&v)[NS], int role)
+{
+    sort_network<NS>(v);
+    // ---- merge the LPP sorted runs: lane r ends up with ranks [r*NS, r*NS+NS) ----
+    // (zonal: the final half-cleaners only order the ends of each lane, see half_clean_ends)
+    constexpr int KEEP = 16;
+    static_assert(kZone + kPadMax <= KEEP, "zones must lie inside the sorted ends");
+    cross_stage<NS, kSwap1, true>(v, (role & 1) == 0);
+    if constexpr (ENDS_ONLY && LPP == 2) half_clean_ends<NS, NS / 2, KEEP>(v);
+    else                             half_clean<NS, NS / 2>(v);
+    if constexpr (LPP == 4) {
+        cross_stage<NS, kMirror, true>(v, role < 2);
+        cross_stage<NS, kSwap1, false>(v, (role & 1) == 0);
+        if constexpr (ENDS_ONLY) half_clean_ends<NS, NS / 2, KEEP>(v);
+        else                 half_clean<NS, NS / 2>(v);
+    }
+}
+
 // Gather one pixel's frames into the LPP lanes that share it (128 per lane), sort every
 // lane's column and merge the runs: afterwards lane r holds global ranks [r*NS, r*NS+NS)
 // (+Inf for missing samples at the top).  Returns the number of valid samples of the pixel.
@@ -198,20 +220,7 @@ int nan_cnt = 0;
             });
         }
     }
-    sort_network<NS>(v);
-    // ---- merge the LPP sorted runs: lane r ends up with ranks [r*NS, r*NS+NS) ----
-    // (zonal: the final half-cleaners only order the ends of each lane, see half_clean_ends)
-    constexpr int KEEP = 16;
-    static_assert(kZone + kPadMax <= KEEP, "zones must lie inside the sorted ends");
-    cross_stage<NS, kSwap1, true>(v, (role & 1) == 0);
-    if constexpr (ENDS_ONLY && LPP == 2) half_clean_ends<NS, NS / 2, KEEP>(v);
-    else                             half_clean<NS, NS / 2>(v);
-    if constexpr (LPP == 4) {
-        cross_stage<NS, kMirror, true>(v, role < 2);
-        cross_stage<NS, kSwap1, false>(v, (role & 1) == 0);
-        if constexpr (ENDS_ONLY) half_clean_ends<NS, NS / 2, KEEP>(v);
-        else                 half_clean<NS, NS / 2>(v);
-    }
+    ml_sort_merge<LPP, NS, ENDS_ONLY>(v, role);
     return quad_sum<LPP>(NS - nan_cnt);
 }
 

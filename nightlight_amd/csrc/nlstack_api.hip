@@ -498,7 +498,9 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
         h->last_has_counters = false;
         h->last_used_fast = false;
-    } else if (!h->force_exact && h->d_fb_list && nl::mad_fast_supported(mode, weighted, a.n_frames)) {
+    } else if (!h->force_exact && h->d_fb_list &&
+               (nl::mad_fast_supported(mode, weighted, a.n_frames) ||
+                (mode == NL_ST_MAD_SIGMA && nl::fast_ml_supported(mode, weighted, a.n_frames, a.npix)))) {
         // register-resident MAD clipping: counters exact (the bounds come from two medians);
         // pixels with a non-finite median are replayed by the LDS kernel
         nl::FastArgs f;
@@ -506,7 +508,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         f.fb_list = h->d_fb_list;
         f.fb_count = h->d_fb_count;
         f.fb_capacity = (unsigned)h->npix;
-        NL_HIP(nl::launch_stack_mad_fast(a, f, h->stream, &h->last_kernel));
+        if (a.n_frames <= 128) NL_HIP(nl::launch_stack_mad_fast(a, f, h->stream, &h->last_kernel));
+        else                   NL_HIP(nl::launch_stack_mad_ml(a, f, h->stream, &h->last_kernel));
         NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
         {
             int lanes = 0;

@@ -408,11 +408,119 @@ hipError_t launch_stack_median_ml(const StackArgs &args, hipStream_t stream, con
     return hipGetLastError();
 }
 
+// StackMADSigma (stack.go:536-605) for 129..512 frames, as stack_mad_fast_kernel: merged
+// column -> median; column := |x - median| -> sort + merge again -> MAD; second read of the
+// pixel's frames (every lane its own) for the clip counts and the mean of the survivors.
+template <int LPP>
+__global__ __launch_bounds__(256) void stack_mad_ml_kernel(StackArgs p, FastArgs q)
+{
+    constexpr int NS = kMlNS;
+    const int lane = threadIdx.x & 63;
+    const int role = threadIdx.x % LPP;
+    const int64_t pix = (int64_t)blockIdx.x * (blockDim.x / LPP) + threadIdx.x / LPP;
+    const bool on = pix < p.npix;
+    int N = p.n_frames;
+    asm volatile("" : "+s"(N));
+    float v[NS];
+    const int n = ml_gather_sorted<LPP, NS, false>(p.frames, p.stride, N, on, pix, role, v);
+    const int kk = n >> 1;
+    const float upper = pick_rank<LPP, NS, NS, NS>(v, kk, role, 0);
+    const float lower = pick_rank<LPP, NS, NS, NS>(v, kk > 0 ? kk - 1 : 0, role, 0);
+    const float median = (n & 1) ? upper : 0.5f * (lower + upper);
+    const bool degenerate = n > 0 && !(__builtin_fabsf(median) < __builtin_inff());
+    const float msafe = degenerate ? 0.0f : median;
+    static_chunks<0, NS, 16>([&](auto K) NL_INL {
+        constexpr int k = decltype(K)::value;
+        v[k] = __builtin_fabsf(v[k] - msafe);
+    });
+    ml_sort_merge<LPP, NS, false>(v, role);
+    const float dupper = pick_rank<LPP, NS, NS, NS>(v, kk, role, 0);
+    const float dlower = pick_rank<LPP, NS, NS, NS>(v, kk > 0 ? kk - 1 : 0, role, 0);
+    const float mad = (n & 1) ? dupper : 0.5f * (dlower + dupper);
+    const float sd = mad * 1.4826f;
+    const float t_lo = p.sig_lo * sd, t_hi = p.sig_hi * sd;
+    const float lo = median - t_lo, hi = median + t_hi;
+
+    // second read: lane role r takes frames r, r+LPP, ... again (clipped descriptors as in the gather)
+    int N2 = p.n_frames;
+    asm volatile("" : "+s"(N2));
+    int frame_bytes = (int)(p.stride * (int64_t)sizeof(float));
+    asm volatile("" : "+s"(frame_bytes));
+    const int voff = (int)((unsigned)(on ? pix : 0) * 4u) + role * frame_bytes;
+    static_chunks<0, NS, 4>([&](auto K) NL_INL {
+        constexpr int k = decltype(K)::value;
+        const int avail = min(max(N2 - k * LPP, 0), LPP);
+        const char *gb = reinterpret_cast<const char *>(p.frames) + (int64_t)(k * LPP) * frame_bytes;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gb), 0, avail * frame_bytes, 0x00020000);
+        v[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
+    });
+    float f_lo = 0.0f, f_hi = 0.0f, f_kept = 0.0f, sum = 0.0f;
+    static_chunks<0, NS, 4>([&](auto K) NL_INL {
+        constexpr int k = decltype(K)::value;
+        const float x = v[k];
+        const bool present = (k * LPP + role < N2) && (x == x);
+        const bool below = present && x < lo;
+        const bool above = present && !below && x > hi;
+        const bool keep = present && !below && !above;
+        f_lo += below ? 1.0f : 0.0f;
+        f_hi += above ? 1.0f : 0.0f;
+        f_kept += keep ? 1.0f : 0.0f;
+        sum += keep ? x : 0.0f;
+        asm volatile("" : "+v"(f_lo), "+v"(f_hi), "+v"(f_kept), "+v"(sum));
+    });
+    int c_lo = (int)quad_sum<LPP>(f_lo), c_hi = (int)quad_sum<LPP>(f_hi);
+    float res = quad_sum<LPP>(sum) / quad_sum<LPP>(f_kept);
+    if (n == 0) res = p.ref_loc;
+    const bool rep = on && role == 0;
+    const bool to_exact = rep && degenerate;
+    if (rep && !to_exact) p.out[pix] = res;
+    if (!rep || to_exact || n == 0) { c_lo = 0; c_hi = 0; }
+    const unsigned long long em = __ballot(to_exact);
+    if (em) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(q.fb_count, (unsigned)__popcll(em));
+        base = __shfl(base, 0, 64);
+        const unsigned slot = base + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
+        if (to_exact && slot < q.fb_capacity) q.fb_list[slot] = (unsigned)pix;
+    }
+    __shared__ int s_lo[4], s_hi[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c_lo += __shfl_xor(c_lo, o, 64);
+        c_hi += __shfl_xor(c_hi, o, 64);
+    }
+    if (lane == 0) { s_lo[threadIdx.x >> 6] = c_lo; s_hi[threadIdx.x >> 6] = c_hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t_l = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3];
+        const int t_h = s_hi[0] + s_hi[1] + s_hi[2] + s_hi[3];
+        unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+        if (t_l) atomicAdd(slot + 0, (unsigned long long)t_l);
+        if (t_h) atomicAdd(slot + 1, (unsigned long long)t_h);
+    }
+}
+
+hipError_t launch_stack_mad_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name)
+{
+    if (args.n_frames <= 2 * kMlNS) {
+        *name = "stack_mad_ml_kernel<2>";
+        hipLaunchKernelGGL(stack_mad_ml_kernel<2>, dim3((unsigned)((args.npix + 127) / 128)), dim3(256), 0, stream, args,
+                           fargs);
+    } else {
+        *name = "stack_mad_ml_kernel<4>";
+        hipLaunchKernelGGL(stack_mad_ml_kernel<4>, dim3((unsigned)((args.npix + 63) / 64)), dim3(256), 0, stream, args,
+                           fargs);
+    }
+    return hipGetLastError();
+}
+
 int fast_ml_supported(int mode, bool weighted, int n_frames, int64_t npix)
 {
     // 4 frames of the tile must be addressable with a 31-bit buffer offset
     if (n_frames <= 128 || n_frames > 512 || npix >= ((int64_t)1 << 27)) return 0;
     if (mode == NL_ST_MEDIAN) return 1;
+    if (mode == NL_ST_MAD_SIGMA) return weighted ? 0 : 1;
     return ((mode == NL_ST_SIGMA || mode == NL_ST_WINSOR_SIGMA) && !weighted) ? 1 : 0;
 }
 

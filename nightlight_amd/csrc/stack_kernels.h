@@ -70,6 +70,7 @@ hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs,
 // ---- stack_fast_ml.hip (129..512 frames, 2 or 4 lanes per pixel) ----
 int fast_ml_supported(int mode, bool weighted, int n_frames, int64_t npix);
 hipError_t launch_stack_median_ml(const StackArgs &args, hipStream_t stream, const char **name);
+hipError_t launch_stack_mad_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name);
 hipError_t launch_stack_sigma_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
                                  const char **name, hipEvent_t dominant_done, bool winsor,
                                  AfterDominant after_dominant, void *user);

@@ -67,9 +67,12 @@ func (op *OpStack) Apply(f []*fits.Image, c *ops.Context) (result *fits.Image, e
 	defer C.nl_stack_destroy(h)
 
 	// one cgo call per Go slice: [][]float32 cannot cross cgo, and the copy
-	// builds the planar [N][H*W] device layout on the way
+	// builds the planar [N][H*W] device layout on the way.  The asynchronous
+	// variant copies the slice into a pinned staging buffer before it returns
+	// (no Go pointer is retained) and lets the DMA of frame i overlap the
+	// staging of frame i+1; nl_stack_run waits for the uploads on the device.
 	for i, l := range f {
-		if rc := C.nl_stack_upload_frame(h, C.int(i), (*C.float)(unsafe.Pointer(&l.Data[0]))); rc != C.NL_OK {
+		if rc := C.nl_stack_upload_frame_async(h, C.int(i), (*C.float)(unsafe.Pointer(&l.Data[0]))); rc != C.NL_OK {
 			return nil, lastError()
 		}
 	}

@@ -34,6 +34,18 @@ for i in range(cases):
                          ties=bool(rng.integers(2)), nan_border=bool(rng.integers(2)))
     if rng.random() < 0.3 and mode != 4:
         frames[int(rng.integers(n)), int(rng.integers(width * height))] = np.inf * (1 if rng.random() < 0.5 else -1)
+    r = rng.random()
+    if r < 0.06:
+        sl = float(rng.choice([-1.0, 0.0, 0.01, 20.0]))       # degenerate bounds (negative sigma: quirk Q6)
+    elif r < 0.12:
+        sh = float(rng.choice([-1.0, 0.0, 0.01, 20.0]))
+    r = rng.random()
+    if r < 0.05:
+        frames = (frames * np.float32(1e-36)).astype(np.float32)      # subnormal variances
+    elif r < 0.10:
+        frames = (frames * np.float32(1e30)).astype(np.float32)       # squares overflow
+    elif r < 0.15:
+        frames[:, : width * height // 3] = np.float32(rng.uniform(-5, 5))   # constant pixels
     weights = None
     if mode in (1, 2, 3) and rng.random() < 0.25:
         weights = rng.uniform(0.2, 1.0, n).astype(np.float32)

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void stack_median_fast_kernel(StackArgs p, Fas
 // (for some inputs it runs off the array and panics).  Such a pixel goes to the exact
 // kernel, which follows the reference step by step where that is defined.
 template <int NS>
-__global__ __launch_bounds__(256) void stack_mad_fast_kernel(StackArgs p, FastArgs q)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS > 96 ? 3 : 1, 8)))
+void stack_mad_fast_kernel(StackArgs p, FastArgs q)
 {
     const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool on = pix < p.npix;

@@ -376,7 +376,8 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
 // exactly (order independent); both middle ranks are looked up over whole lanes, so any
 // number of missing samples is fine and nothing is handed over.
 template <int LPP>
-__global__ __launch_bounds__(256) void stack_median_ml_kernel(StackArgs p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8)))
+void stack_median_ml_kernel(StackArgs p)
 {
     constexpr int NS = kMlNS;
     const int role = threadIdx.x % LPP;
@@ -412,7 +413,8 @@ hipError_t launch_stack_median_ml(const StackArgs &args, hipStream_t stream, con
 // column -> median; column := |x - median| -> sort + merge again -> MAD; second read of the
 // pixel's frames (every lane its own) for the clip counts and the mean of the survivors.
 template <int LPP>
-__global__ __launch_bounds__(256) void stack_mad_ml_kernel(StackArgs p, FastArgs q)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8)))
+void stack_mad_ml_kernel(StackArgs p, FastArgs q)
 {
     constexpr int NS = kMlNS;
     const int lane = threadIdx.x & 63;

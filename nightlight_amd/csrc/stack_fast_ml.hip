@@ -32,7 +32,7 @@ namespace nl {
 // Valid while more than LAST*128 + 8 samples are present.
 // (zonal sigma: the allocator lands one register above the 168 that let 3 waves share a SIMD)
 template <int LPP, bool ZONAL, bool WINSOR, bool WIDE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZONAL && !WINSOR ? 3 : 1, 8)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZONAL ? (WINSOR ? 2 : 3) : 1, 8)))
 void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
 {
     constexpr int NS = kMlNS, NT = NS * LPP;

@@ -87,17 +87,40 @@ struct OemNetwork {
     static constexpr Table kTable = make();
 };
 
+// ---- the networks as executed: 2- and 3-input operations -------------------
+// v_min_f32 / v_max_f32 and v_min3 / v_med3 / v_max3 all issue at the same (half) rate on gfx950,
+// so a network costs its instruction count.  tools/gen_sort_tables.py rewrites each network
+// (the comparator lists above / ZonalNetwork below) into operations on numbered slots, inlining
+// an intermediate min or max into the comparator that consumes it wherever the 0-1 principle
+// proves  CE(min(x,y), z) == {min3(x,y,z), med3(x,y,z)}  (resp. {med3, max3} for max(x,y)):
+// about a quarter fewer instructions.  kOut[k] = slot holding rank k at the end.
+struct FusedOp { unsigned char kind; short dst, a, b, c; };   // kind: 0 min, 1 max, 2 min3, 3 med3, 4 max3
+template <int NS, int E0, int E1, int E2, int E3>
+struct FusedNet;                                               // specialisations: sort_tables.inc
+#include "sort_tables.inc"
+
+template <class Net, int NS>
+__device__ __forceinline__ void run_network(float (&v)[NS])
+{
+    float w[Net::kSlots];
+    static_range<0, NS>([&](auto K) NL_INL { w[decltype(K)::value] = v[decltype(K)::value]; });
+    static_chunks<0, Net::kCount, 64>([&](auto I) NL_INL {
+        constexpr FusedOp op = Net::kOps[decltype(I)::value];
+        if constexpr (op.kind == 0)      w[op.dst] = fminf(w[op.a], w[op.b]);
+        else if constexpr (op.kind == 1) w[op.dst] = fmaxf(w[op.a], w[op.b]);
+        else if constexpr (op.kind == 2) w[op.dst] = fminf(fminf(w[op.a], w[op.b]), w[op.c]);
+        else if constexpr (op.kind == 3) w[op.dst] = __builtin_amdgcn_fmed3f(w[op.a], w[op.b], w[op.c]);
+        else                             w[op.dst] = fmaxf(fmaxf(w[op.a], w[op.b]), w[op.c]);
+    });
+    static_range<0, NS>([&](auto K) NL_INL { v[decltype(K)::value] = w[Net::kOut[decltype(K)::value]]; });
+}
+
 template <int NS>
 __device__ __forceinline__ void sort_network(float (&v)[NS])
 {
-    using Net = OemNetwork<NS>;
-    static_chunks<0, Net::kCount, 64>([&](auto I) NL_INL {
-        constexpr CePair ce = Net::kTable.e[decltype(I)::value];
-        const float lo = fminf(v[ce.lo], v[ce.hi]);
-        const float hi = fmaxf(v[ce.lo], v[ce.hi]);
-        v[ce.lo] = lo;
-        v[ce.hi] = hi;
-    });
+    using Net = FusedNet<NS, 0, 0, 0, 0>;
+    static_assert(Net::kComparators == OemNetwork<NS>::kCount, "sort_tables.inc does not match OemNetwork");
+    run_network<Net, NS>(v);
 }
 
 // The zonal kernels need exact ranks only at the ends (clip zones) and around
@@ -144,14 +167,10 @@ struct ZonalSort {
     template <int NS>
     static __device__ __forceinline__ void apply(float (&v)[NS])
     {
-        using Net = ZonalNetwork<NS, E0, E1, E2, E3>;
-        static_chunks<0, Net::kCount, 64>([&](auto I) NL_INL {
-            constexpr CePair ce = Net::kTable.e[decltype(I)::value];
-            const float lo = fminf(v[ce.lo], v[ce.hi]);
-            const float hi = fmaxf(v[ce.lo], v[ce.hi]);
-            v[ce.lo] = lo;
-            v[ce.hi] = hi;
-        });
+        using Net = FusedNet<NS, E0, E1, E2, E3>;
+        static_assert(Net::kComparators == ZonalNetwork<NS, E0, E1, E2, E3>::kCount,
+                      "sort_tables.inc does not match ZonalNetwork");
+        run_network<Net, NS>(v);
     }
 };
 

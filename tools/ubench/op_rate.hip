@@ -43,6 +43,11 @@ OP2(alignbit, "v_alignbit_b32 %0, %0, %1, %2")
 OP2(bfi, "v_bfi_b32 %0, %0, %1, %2")
 OP2(sub_f32, "v_sub_f32 %0, %0, %1")
 OP2(mul_f32, "v_mul_f32 %0, %0, %1")
+OP2(sad_u32, "v_sad_u32 %0, %0, %1, %2")
+OP2(or3_b32, "v_or3_b32 %0, %0, %1, %2")
+OP2(add3_u32, "v_add3_u32 %0, %0, %1, %2")
+OP2(max_u32, "v_max_u32 %0, %0, %1")
+OP2(sub_u32, "v_sub_u32 %0, %0, %1")
 
 typedef void (*kern_t)(unsigned *, int);
 struct Entry { const char *name; kern_t k; };
@@ -58,7 +63,7 @@ int main()
                   {"v_fma_f32", k_fma_f32}, {"v_min3_f32", k_min3_f32}, {"v_med3_f32", k_med3_f32}, {"v_min3_i32", k_min3_i32},
                   {"v_med3_i32", k_med3_i32}, {"v_cndmask", k_cndmask}, {"v_cmp_lt_f32", k_cmp_lt_f32}, {"v_cmp_lt_u32", k_cmp_lt_u32},
                   {"v_pk_min_u16", k_pk_min_u16}, {"v_pk_min_f16", k_pk_min_f16}, {"v_xor_b32", k_xor_b32}, {"v_mov_b32", k_mov_b32},
-                  {"v_perm_b32", k_perm_b32}, {"v_alignbit", k_alignbit}, {"v_bfi_b32", k_bfi}};
+                  {"v_perm_b32", k_perm_b32}, {"v_alignbit", k_alignbit}, {"v_bfi_b32", k_bfi}, {"v_sad_u32", k_sad_u32}, {"v_or3_b32", k_or3_b32}, {"v_add3_u32", k_add3_u32}, {"v_max_u32", k_max_u32}, {"v_sub_u32", k_sub_u32}};
     const int iters = 500;
     for (int wps : {1, 2, 3, 4, 8}) {
         printf("waves/SIMD=%d:", wps);

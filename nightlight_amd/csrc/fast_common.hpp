@@ -99,28 +99,39 @@ template <int NS, int E0, int E1, int E2, int E3>
 struct FusedNet;                                               // specialisations: sort_tables.inc
 #include "sort_tables.inc"
 
-template <class Net, int NS>
+// ASM: the 2-input and min3 / max3 operations are written as the instructions themselves --
+// fminf / fmaxf put a canonicalising v_max_f32 x, x, x in front of every value that comes
+// straight from memory (the column holds no NaN here, so there is nothing to quiet).  Leaving
+// them to the compiler instead lets it schedule more freely, which the MAD kernel (two sorts at
+// 168 registers) prefers.
+template <class Net, int NS, bool ASM = true>
 __device__ __forceinline__ void run_network(float (&v)[NS])
 {
     float w[Net::kSlots];
     static_range<0, NS>([&](auto K) NL_INL { w[decltype(K)::value] = v[decltype(K)::value]; });
     static_chunks<0, Net::kCount, 64>([&](auto I) NL_INL {
         constexpr FusedOp op = Net::kOps[decltype(I)::value];
-        if constexpr (op.kind == 0)      w[op.dst] = fminf(w[op.a], w[op.b]);
-        else if constexpr (op.kind == 1) w[op.dst] = fmaxf(w[op.a], w[op.b]);
-        else if constexpr (op.kind == 2) w[op.dst] = fminf(fminf(w[op.a], w[op.b]), w[op.c]);
-        else if constexpr (op.kind == 3) w[op.dst] = __builtin_amdgcn_fmed3f(w[op.a], w[op.b], w[op.c]);
-        else                             w[op.dst] = fmaxf(fmaxf(w[op.a], w[op.b]), w[op.c]);
+        float r;
+        if constexpr (op.kind == 3)      r = __builtin_amdgcn_fmed3f(w[op.a], w[op.b], w[op.c]);
+        else if constexpr (!ASM && op.kind == 0) r = fminf(w[op.a], w[op.b]);
+        else if constexpr (!ASM && op.kind == 1) r = fmaxf(w[op.a], w[op.b]);
+        else if constexpr (!ASM && op.kind == 2) r = fminf(fminf(w[op.a], w[op.b]), w[op.c]);
+        else if constexpr (!ASM && op.kind == 4) r = fmaxf(fmaxf(w[op.a], w[op.b]), w[op.c]);
+        else if constexpr (op.kind == 0) asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(w[op.a]), "v"(w[op.b]));
+        else if constexpr (op.kind == 1) asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(w[op.a]), "v"(w[op.b]));
+        else if constexpr (op.kind == 2) asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(w[op.a]), "v"(w[op.b]), "v"(w[op.c]));
+        else                             asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(w[op.a]), "v"(w[op.b]), "v"(w[op.c]));
+        w[op.dst] = r;
     });
     static_range<0, NS>([&](auto K) NL_INL { v[decltype(K)::value] = w[Net::kOut[decltype(K)::value]]; });
 }
 
-template <int NS>
+template <int NS, bool ASM = true>
 __device__ __forceinline__ void sort_network(float (&v)[NS])
 {
     using Net = FusedNet<NS, 0, 0, 0, 0>;
     static_assert(Net::kComparators == OemNetwork<NS>::kCount, "sort_tables.inc does not match OemNetwork");
-    run_network<Net, NS>(v);
+    run_network<Net, NS, ASM>(v);
 }
 
 // The zonal kernels need exact ranks only at the ends (clip zones) and around
@@ -158,10 +169,12 @@ struct ZonalNetwork {
     static constexpr int kCount = kTable.n;
 };
 
-struct FullSort {
+template <bool ASM>
+struct FullSortT {
     template <int NS>
-    static __device__ __forceinline__ void apply(float (&v)[NS]) { sort_network<NS>(v); }
+    static __device__ __forceinline__ void apply(float (&v)[NS]) { sort_network<NS, ASM>(v); }
 };
+using FullSort = FullSortT<true>;
 template <int E0, int E1, int E2, int E3>
 struct ZonalSort {
     template <int NS>

@@ -134,7 +134,7 @@ void stack_mad_fast_kernel(StackArgs p, FastArgs q)
     int N = p.n_frames;
     asm volatile("" : "+s"(N));
     float v[NS];
-    const int n = gather_sorted<NS>(p.frames, p.stride, N, boff, v);
+    const int n = gather_sorted<NS, 16, FullSortT<false>>(p.frames, p.stride, N, boff, v);
     const int kk = n >> 1;                                   // qsort.go:70: k = (n>>1)+1, 1-based
     const float upper = pick<0, NS>(v, kk);
     const float lower = pick<0, NS>(v, kk > 0 ? kk - 1 : 0);
@@ -145,7 +145,7 @@ void stack_mad_fast_kernel(StackArgs p, FastArgs q)
         constexpr int k = decltype(K)::value;
         v[k] = __builtin_fabsf(v[k] - msafe);                // stack.go:566-571 (pads stay +Inf)
     });
-    sort_network<NS>(v);
+    sort_network<NS, false>(v);
     const float dupper = pick<0, NS>(v, kk);
     const float dlower = pick<0, NS>(v, kk > 0 ? kk - 1 : 0);
     const float mad = (n & 1) ? dupper : 0.5f * (dlower + dupper);

@@ -209,6 +209,23 @@ __device__ __forceinline__ float pick(const float (&v)[NS], int idx)
     return r;
 }
 
+// v[idx] and v[idx-1] with one compare per candidate (the two ranks a median reads);
+// idx in [B, E); lower is only meaningful for idx > B
+template <int B, int E, int NS>
+__device__ __forceinline__ void pick_pair(const float (&v)[NS], int idx, float &lower, float &upper)
+{
+    float up = v[B], lo = v[B];
+    static_range<B + 1, E>([&](auto K) NL_INL {
+        constexpr int k = decltype(K)::value;
+        if constexpr (((k - B) & 7) == 0) idx = opaque(idx);
+        const bool hit = idx == k;
+        up = hit ? v[k] : up;
+        lo = hit ? v[k - 1] : lo;
+    });
+    upper = up;
+    lower = lo;
+}
+
 // NaN -> +Inf, everything else unchanged: IEEE minNum(NaN, Inf) = Inf.  Written
 // as the instruction itself so that it stays ONE VALU op without a lane mask.
 __device__ __forceinline__ float nan_to_inf(float x)

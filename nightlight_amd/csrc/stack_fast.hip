@@ -76,11 +76,9 @@ __global__ __launch_bounds__(256) void stack_median_fast_kernel(StackArgs p, Fas
         float upper, lower;
         if constexpr (WINDOW) {
             hand_over = on && n < NS - kMedianPad;          // kk-1 >= W0 and kk < W1 otherwise
-            upper = pick<W0, W1>(v, kk);
-            lower = pick<W0, W1>(v, kk - 1);
+            pick_pair<W0, W1>(v, kk, lower, upper);
         } else {
-            upper = pick<0, NS>(v, kk);
-            lower = pick<0, NS>(v, kk > 0 ? kk - 1 : 0);
+            pick_pair<0, NS>(v, kk, lower, upper);
         }
         float res = (n & 1) ? upper : 0.5f * (lower + upper);
         if (n == 0) res = p.ref_loc;
@@ -136,8 +134,8 @@ void stack_mad_fast_kernel(StackArgs p, FastArgs q)
     float v[NS];
     const int n = gather_sorted<NS, 16, FullSortT<false>>(p.frames, p.stride, N, boff, v);
     const int kk = n >> 1;                                   // qsort.go:70: k = (n>>1)+1, 1-based
-    const float upper = pick<0, NS>(v, kk);
-    const float lower = pick<0, NS>(v, kk > 0 ? kk - 1 : 0);
+    float upper, lower;
+    pick_pair<0, NS>(v, kk, lower, upper);
     const float median = (n & 1) ? upper : 0.5f * (lower + upper);
     const bool degenerate = n > 0 && !(__builtin_fabsf(median) < __builtin_inff());
     const float msafe = degenerate ? 0.0f : median;
@@ -146,8 +144,8 @@ void stack_mad_fast_kernel(StackArgs p, FastArgs q)
         v[k] = __builtin_fabsf(v[k] - msafe);                // stack.go:566-571 (pads stay +Inf)
     });
     sort_network<NS, false>(v);
-    const float dupper = pick<0, NS>(v, kk);
-    const float dlower = pick<0, NS>(v, kk > 0 ? kk - 1 : 0);
+    float dupper, dlower;
+    pick_pair<0, NS>(v, kk, dlower, dupper);
     const float mad = (n & 1) ? dupper : 0.5f * (dlower + dupper);
     const float sd = mad * 1.4826f;                          // stack.go:574
     const float t_lo = p.sig_lo * sd, t_hi = p.sig_hi * sd;
@@ -387,8 +385,8 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
             // ---- exact median (qsort.go:68-82): sorted column, position lookup ----
             // zonal: a in [0,ZL), b in (ZH,NS]  =>  kk in [ZH/2, ZL-1+NS/2]
             const int kk = a + (cnt >> 1);
-            const float upper = pick<W0, W1>(v, kk);
-            const float lower = pick<W0, W1>(v, kk - 1);
+            float upper, lower;
+            pick_pair<W0, W1>(v, kk, lower, upper);
             const float median = (cnt & 1) ? upper : 0.5f * (lower + upper);
 
             if constexpr (WINSOR) {

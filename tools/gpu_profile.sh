@@ -15,7 +15,7 @@ repo=$(pwd)
 out=$repo/gpurun_out
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-steps="--steps 5 --warmup 2 --no-cpu"
+steps="--steps 20 --warmup 5 --no-cpu"      # enough passes for the clocks to settle
 
 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats" -o p -- \
     python "$repo/bench.py" $steps "$@" > "$out/${tag}_bench.json" 2> "$out/${tag}_stats.log"

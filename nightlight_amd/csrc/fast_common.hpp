@@ -243,7 +243,7 @@ __device__ __forceinline__ float nan_to_inf(float x)
 // last frame, so unused positions re-read a valid address.
 // GAP: the caller guarantees N > NS - GAP (distance to its next smaller network size).
 // SORT: FullSort, or ZonalSort<...> where only part of the order is needed.
-template <int NS, int GAP = 16, class SORT = FullSort>
+template <int NS, int GAP = 16, class SORT = FullSort, bool NT = false>
 __device__ __forceinline__ int gather_sorted(const float *frames, int64_t stride, int N,
                                              unsigned boff, float (&v)[NS])
 {
@@ -254,6 +254,10 @@ __device__ __forceinline__ int gather_sorted(const float *frames, int64_t stride
     // turned into missing samples below).
     const int64_t frame_bytes = stride * (int64_t)sizeof(float);
     const int last = N - 1;
+    // NT: cache policy nt (aux = 2) for kernels that read every frame byte exactly once per pass --
+    // the lines need not stay in L2 / MALL: the median kernel gains 6 % (80 % of the 8 TB/s peak).
+    // Not for the MAD kernel (its second read of the column hits the MALL) nor for the multi-lane
+    // gathers (neighbouring waves share 128-byte lines through L2): both measured slower with nt.
     static_chunks<0, NS / 4, 4>([&](auto C) NL_INL {
         constexpr int c0 = 4 * decltype(C)::value;
         const int f0 = min(c0, last);
@@ -263,7 +267,7 @@ __device__ __forceinline__ int gather_sorted(const float *frames, int64_t stride
         static_range<0, 4>([&](auto U) NL_INL {
             constexpr int k = c0 + decltype(U)::value;
             const int soff = (min(k, last) - f0) * (int)frame_bytes;
-            v[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)boff, soff, 0));
+            v[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)boff, soff, NT ? 2 : 0));
         });
     });
     // unused positions k >= N (N > NS - GAP by the choice of NS) become NaN = missing

@@ -38,7 +38,11 @@ __global__ __launch_bounds__(256) void stack_mean_vec4_kernel(StackArgs p)
         for (; k + 8 <= p.n_frames; k += 8) {
             float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = fr[(int64_t)(k + u) * stride4];
+            for (int u = 0; u < 8; u++) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(&fr[(int64_t)(k + u) * stride4]));
+                v[u] = make_float4(t.x, t.y, t.z, t.w);
+            }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const float w = W ? p.weights[k + u] : 0.0f;

@@ -222,12 +222,17 @@ void stack_mad_fast_kernel(StackArgs p, FastArgs q)
 // ZONAL = true : grid covers the tile, lane = pixel blockIdx*256+thread;
 // ZONAL = false: grid-stride over q.in_list (pixels handed over by the zonal
 //                kernel), any number of missing / clipped samples.
-template <int NS, bool ZONAL, bool WINSOR>
+// TIGHT (zonal sigma only): the stack has exactly NS frames, so the only missing samples are a
+//                pixel's own NaNs -- the high zone reserves no positions for them (a third
+//                fewer zone positions to mask, count and re-sum every clipping round); a lane
+//                whose NaNs leave no survivor in the high zone goes to the generic pass as before.
+template <int NS, bool ZONAL, bool WINSOR, bool TIGHT>
 __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
 {
+    static_assert(!TIGHT || (ZONAL && !WINSOR), "TIGHT is a variant of the zonal sigma kernel");
     // zone widths: 8 clipped + 8 missing samples per lane for the larger
     // networks, 4 + 4 for the small ones
-    constexpr int KZ = NS >= 48 ? kZone : 4, KP = NS >= 48 ? kPadMax : 4;
+    constexpr int KZ = NS >= 48 ? kZone : 4, KP = TIGHT ? 0 : (NS >= 48 ? kPadMax : 4);
     static_assert(!ZONAL || NS >= 24, "zonal passes need room between the zones");
     constexpr int ZL = KZ;                                    // low zone  = positions [0, ZL)
     constexpr int ZH = ZONAL ? NS - KZ - KP : NS;             // high zone = positions [ZH, NS)
@@ -670,12 +675,13 @@ hipError_t launch_stack_mad_fast(const StackArgs &args, const FastArgs &fargs, h
 // smallest network size with a zonal instantiation
 constexpr int kZonalMinSize = 24;
 
-// kernel names as rocprofv3 prints them (template arguments: NS, ZONAL, WINSOR)
-template <int NS, bool ZONAL, bool WINSOR>
+// kernel names as rocprofv3 prints them (template arguments: NS, ZONAL, WINSOR, TIGHT)
+template <int NS, bool ZONAL, bool WINSOR, bool TIGHT>
 static const char *sigma_kernel_name()
 {
     static const std::string name = std::string("stack_sigma_fast_kernel<") + std::to_string(NS) + ", " +
-                                    (ZONAL ? "true" : "false") + ", " + (WINSOR ? "true" : "false") + ">";
+                                    (ZONAL ? "true" : "false") + ", " + (WINSOR ? "true" : "false") + ", " +
+                                    (TIGHT ? "true" : "false") + ">";
     return name.c_str();
 }
 
@@ -689,9 +695,15 @@ static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned t
     f.in_count = nullptr;
     f.in_capacity = 0;
     if constexpr (NS >= kZonalMinSize) {
-        *name = sigma_kernel_name<NS, true, WINSOR>();
-        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true, WINSOR>), dim3(tile_blocks), dim3(256), 0,
-                           stream, args, f);
+        if (!WINSOR && args.n_frames == NS) {
+            *name = sigma_kernel_name<NS, true, false, true>();
+            hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true, false, true>), dim3(tile_blocks), dim3(256), 0,
+                               stream, args, f);
+        } else {
+            *name = sigma_kernel_name<NS, true, WINSOR, false>();
+            hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true, WINSOR, false>), dim3(tile_blocks), dim3(256), 0,
+                               stream, args, f);
+        }
         if (dominant_done) (void)hipEventRecord(dominant_done, stream);
         if (after) after(user);
         // generic pass over the pixels the zonal waves handed over (its length
@@ -700,12 +712,12 @@ static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned t
         f.in_count = fargs.gen_count;
         f.in_capacity = fargs.gen_capacity;
         const unsigned gblocks = tile_blocks < kGenericGrid ? tile_blocks : kGenericGrid;
-        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false, WINSOR>), dim3(gblocks), dim3(256), 0,
+        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false, WINSOR, false>), dim3(gblocks), dim3(256), 0,
                            stream, args, f);
     } else {
         // small stacks: generic passes are cheap, run them over the whole tile
-        *name = sigma_kernel_name<NS, false, WINSOR>();
-        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false, WINSOR>), dim3(tile_blocks), dim3(256), 0,
+        *name = sigma_kernel_name<NS, false, WINSOR, false>();
+        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false, WINSOR, false>), dim3(tile_blocks), dim3(256), 0,
                            stream, args, f);
         if (dominant_done) (void)hipEventRecord(dominant_done, stream);
         if (after) after(user);

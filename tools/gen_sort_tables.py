@@ -289,8 +289,9 @@ def variants():
         v.append((ns, (0, 0, 0, 0)))                                     # FullSort
         if ns >= 24:                                                     # zonal sigma (stack_fast.hip)
             kz, kp = (K_ZONE, K_PAD_MAX) if ns >= 48 else (4, 4)
-            zl, zh = kz, ns - kz - kp
-            v.append((ns, (zl, zh // 2 - 1, zl + ns // 2 + 1, zh)))
+            for pads in (kp, 0):                                         # 0: the TIGHT variant (exactly ns frames)
+                zl, zh = kz, ns - kz - pads
+                v.append((ns, (zl, zh // 2 - 1, zl + ns // 2 + 1, zh)))
         if ns >= 32:                                                     # median window
             v.append((ns, (0, (ns - K_MEDIAN_PAD) // 2 - 1, ns // 2 + 1, ns)))
     return v

@@ -222,14 +222,14 @@ void stack_mad_fast_kernel(StackArgs p, FastArgs q)
 // ZONAL = true : grid covers the tile, lane = pixel blockIdx*256+thread;
 // ZONAL = false: grid-stride over q.in_list (pixels handed over by the zonal
 //                kernel), any number of missing / clipped samples.
-// TIGHT (zonal sigma only): the stack has exactly NS frames, so the only missing samples are a
+// TIGHT (zonal only): the stack has exactly NS frames, so the only missing samples are a
 //                pixel's own NaNs -- the high zone reserves no positions for them (a third
 //                fewer zone positions to mask, count and re-sum every clipping round); a lane
 //                whose NaNs leave no survivor in the high zone goes to the generic pass as before.
 template <int NS, bool ZONAL, bool WINSOR, bool TIGHT>
 __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
 {
-    static_assert(!TIGHT || (ZONAL && !WINSOR), "TIGHT is a variant of the zonal sigma kernel");
+    static_assert(!TIGHT || ZONAL, "TIGHT is a variant of the zonal kernels");
     // zone widths: 8 clipped + 8 missing samples per lane for the larger
     // networks, 4 + 4 for the small ones
     constexpr int KZ = NS >= 48 ? kZone : 4, KP = TIGHT ? 0 : (NS >= 48 ? kPadMax : 4);
@@ -695,9 +695,9 @@ static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned t
     f.in_count = nullptr;
     f.in_capacity = 0;
     if constexpr (NS >= kZonalMinSize) {
-        if (!WINSOR && args.n_frames == NS) {
-            *name = sigma_kernel_name<NS, true, false, true>();
-            hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true, false, true>), dim3(tile_blocks), dim3(256), 0,
+        if (args.n_frames == NS) {
+            *name = sigma_kernel_name<NS, true, WINSOR, true>();
+            hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true, WINSOR, true>), dim3(tile_blocks), dim3(256), 0,
                                stream, args, f);
         } else {
             *name = sigma_kernel_name<NS, true, WINSOR, false>();

@@ -53,7 +53,7 @@ def test_mode_matches_oracle(nl, oracle, mode, n):
         assert gc == wc, "%s n=%d clip counters %r vs oracle %r" % (MODES[mode], n, gc, wc)
 
 
-@pytest.mark.parametrize("n", [2, 3, 5, 8, 9, 15, 16, 17, 20, 24, 25, 29, 32, 33, 48, 50, 64, 65, 80, 100, 112, 127, 128])
+@pytest.mark.parametrize("n", [2, 3, 5, 8, 9, 15, 16, 17, 20, 24, 25, 29, 32, 33, 48, 50, 64, 65, 80, 96, 100, 112, 127, 128])
 @pytest.mark.parametrize("kappa", [2.75, 1.5])
 def test_fast_sigma_counts_exact_values_close(nl, oracle, n, kappa):
     # default dispatch: register-resident sigma kernel (+ generic pass on the NaN
@@ -69,7 +69,7 @@ def test_fast_sigma_counts_exact_values_close(nl, oracle, n, kappa):
     assert np.max(np.abs(got[ok] - want[ok]) / np.abs(want[ok])) < 2e-6
 
 
-@pytest.mark.parametrize("n", [2, 3, 5, 8, 9, 15, 16, 17, 20, 24, 25, 29, 32, 33, 48, 50, 64, 65, 80, 100, 112, 127, 128])
+@pytest.mark.parametrize("n", [2, 3, 5, 8, 9, 15, 16, 17, 20, 24, 25, 29, 32, 33, 48, 50, 64, 65, 80, 96, 100, 112, 127, 128])
 @pytest.mark.parametrize("kappa", [2.75, 1.5])
 def test_fast_winsor_counts_exact_values_close(nl, oracle, n, kappa):
     # default dispatch for winsorized sigma clipping: the same register-resident
@@ -81,6 +81,28 @@ def test_fast_winsor_counts_exact_values_close(nl, oracle, n, kappa):
     assert close_values(got, want), "fast winsor n=%d: %s" % (n, describe_mismatch(got, want))
     ok = ~np.isnan(want) & (want != 0)
     assert np.max(np.abs(got[ok] - want[ok]) / np.abs(want[ok])) < 2e-6
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("n", [24, 32, 48, 64, 80, 96, 112, 128])
+@pytest.mark.parametrize("nan_frac", [0.0, 0.01, 0.05])
+def test_tight_zonal_variant_exact_sizes(nl, oracle, mode, n, nan_frac):
+    # a stack of exactly NS frames runs the TIGHT instantiation (no high-zone positions
+    # reserved for missing samples): pixels with a few NaNs stay in it with less room to
+    # clip, heavier ones and heavy clipping go to the generic pass -- counters exact either way
+    width, height = 192, 24
+    frames = make_frames(n, width, height, seed=900 + n, nan_frac=nan_frac, hot=0.03, cold=0.01,
+                         nan_border=False, all_nan_patch=False)
+    with nl.StackHandle(n, width, height) as st:
+        st.upload_frames(frames)
+        st.set_exact(False)
+        got, cl, ch = st.run(mode, 2.5, 2.0, 0.0)
+        name = st.last_kernel_name
+    assert name == "stack_sigma_fast_kernel<%d, true, %s, true>" % (n, "true" if mode == 3 else "false"), name
+    rc, want, wl, wh, _ = oracle.stack_apply(mode, frames, None, 2.5, 2.0, 0.0, num_cpu=4)
+    assert rc == 0
+    assert (cl, ch) == (wl, wh), "n=%d mode=%d clip counters %r vs oracle %r" % (n, mode, (cl, ch), (wl, wh))
+    assert close_values(got, want), describe_mismatch(got, want)
 
 
 def test_fast_winsor_clean_frames_and_outliers(nl, oracle):

@@ -109,7 +109,7 @@ __device__ __forceinline__ void run_network(float (&v)[NS])
 {
     float w[Net::kSlots];
     static_range<0, NS>([&](auto K) NL_INL { w[decltype(K)::value] = v[decltype(K)::value]; });
-    static_chunks<0, Net::kCount, 64>([&](auto I) NL_INL {
+    static_chunks<0, Net::kCount, 128>([&](auto I) NL_INL {
         constexpr FusedOp op = Net::kOps[decltype(I)::value];
         float r;
         if constexpr (op.kind == 3)      r = __builtin_amdgcn_fmed3f(w[op.a], w[op.b], w[op.c]);

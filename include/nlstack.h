@@ -100,6 +100,11 @@ int nl_stack_attach_device_frames(nl_stack_t *h, void *device_frames);
 int nl_stack_fill_synthetic(nl_stack_t *h, uint64_t seed);
 /* Downloads frame `idx`'s tile (rows*width floats). */
 int nl_stack_download_tile(nl_stack_t *h, int idx, float *host_tile);
+/* Downloads n_rows rows starting at tile-relative row first_row (n_rows*width
+ * floats) of frame `idx`, or of the result tile of the last finished pass when
+ * idx == -1.  Rows are contiguous in the planar layout, so this is one DMA;
+ * it lets a caller inspect parts of stacks far larger than host memory. */
+int nl_stack_download_rows(nl_stack_t *h, int idx, int first_row, int n_rows, float *host_rows);
 
 /* getWeights (stack.go:231-270).  weights: n_frames floats or NULL = none. */
 int nl_stack_set_weights(nl_stack_t *h, const float *weights);

@@ -32,7 +32,7 @@ EXPORTS = [
     "nl_last_error", "nl_device_count", "nl_version",
     "nl_stack_create", "nl_stack_destroy",
     "nl_stack_upload_frame", "nl_stack_upload_tile", "nl_stack_upload_frame_async", "nl_stack_upload_wait", "nl_stack_frames_device_ptr",
-    "nl_stack_attach_device_frames", "nl_stack_fill_synthetic", "nl_stack_download_tile",
+    "nl_stack_attach_device_frames", "nl_stack_fill_synthetic", "nl_stack_download_tile", "nl_stack_download_rows",
     "nl_stack_set_weights", "nl_weights_from_scalars",
     "nl_stack_run", "nl_stack_run_async", "nl_stack_finish", "nl_stack_result_device_ptr",
     "nl_stack_last_mode", "nl_stack_last_kernel_ms", "nl_stack_last_dominant_kernel_ms",
@@ -87,6 +87,7 @@ def load():
     L.nl_stack_upload_frame.argtypes = [vp, C.c_int, _f32p]
     L.nl_stack_upload_tile.argtypes = [vp, C.c_int, _f32p]
     L.nl_stack_download_tile.argtypes = [vp, C.c_int, _f32p]
+    L.nl_stack_download_rows.argtypes = [vp, C.c_int, C.c_int, C.c_int, _f32p]
     L.nl_stack_frames_device_ptr.argtypes = [vp]
     L.nl_stack_frames_device_ptr.restype = vp
     L.nl_stack_attach_device_frames.argtypes = [vp, vp]

@@ -332,6 +332,20 @@ int nl_stack_download_tile(nl_stack_t *h, int idx, float *host_tile)
     return NL_OK;
 }
 
+int nl_stack_download_rows(nl_stack_t *h, int idx, int first_row, int n_rows, float *host_rows)
+{
+    NL_CHECK_HANDLE(h);
+    NL_SETTLE_UPLOADS(h);
+    if (idx < -1 || idx >= h->n_frames || !host_rows || first_row < 0 || n_rows <= 0 ||
+        (int64_t)first_row + n_rows > h->rows)
+        return fail(NL_ERR_INVALID_ARG, "download_rows: bad index %d, rows [%d,%d) of %d, or null buffer",
+                    idx, first_row, first_row + n_rows, h->rows);
+    const float *src = (idx < 0 ? h->d_out : h->d_frames + (int64_t)idx * h->npix) + (int64_t)first_row * h->width;
+    NL_HIP(hipMemcpyAsync(host_rows, src, (size_t)n_rows * h->width * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    NL_HIP(hipStreamSynchronize(h->stream));
+    return NL_OK;
+}
+
 void *nl_stack_frames_device_ptr(nl_stack_t *h) { return h ? h->d_frames : nullptr; }
 void *nl_stack_result_device_ptr(nl_stack_t *h) { return h ? h->d_out : nullptr; }
 int nl_stack_last_mode(nl_stack_t *h) { return h ? h->last_mode : -1; }
@@ -481,7 +495,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         NL_HIP(nl::launch_stack_mean(weighted, a, h->stream, &h->last_kernel));
         NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
         h->last_has_counters = false;
-    } else if (!h->force_exact && mode == NL_ST_MEDIAN && nl::fast_supported(mode, weighted, a.n_frames)) {
+    } else if (!h->force_exact && mode == NL_ST_MEDIAN && nl::fast_supported(mode, weighted, a.n_frames, a.npix)) {
         // register-resident sorting network, bit-exact; pixels with many missing samples are
         // handed from the pruned-network kernel to the full-sort one
         nl::FastArgs f;
@@ -499,7 +513,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         h->last_has_counters = false;
         h->last_used_fast = false;
     } else if (!h->force_exact && h->d_fb_list &&
-               (nl::mad_fast_supported(mode, weighted, a.n_frames) ||
+               (nl::mad_fast_supported(mode, weighted, a.n_frames, a.npix) ||
                 (mode == NL_ST_MAD_SIGMA && nl::fast_ml_supported(mode, weighted, a.n_frames, a.npix)))) {
         // register-resident MAD clipping: counters exact (the bounds come from two medians);
         // pixels with a non-finite median are replayed by the LDS kernel
@@ -552,7 +566,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
         h->last_has_counters = true;
         h->last_used_fast = true;
-    } else if (!h->force_exact && h->d_fb_list && nl::linfit_fast_supported(mode, a.n_frames)) {
+    } else if (!h->force_exact && h->d_fb_list && nl::linfit_fast_supported(mode, a.n_frames, a.npix)) {
         // register-resident linear fit: bit-exact (sums run in sorted order);
         // only pixels with an infinite sample are replayed by the LDS kernel
         nl::FastArgs f;
@@ -579,7 +593,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         h->last_has_counters = true;
         h->last_used_fast = true;
     } else if (!h->force_exact && h->d_fb_list &&
-               (nl::fast_supported(mode, weighted, a.n_frames) || nl::fast_ml_supported(mode, weighted, a.n_frames, a.npix))) {
+               (nl::fast_supported(mode, weighted, a.n_frames, a.npix) || nl::fast_ml_supported(mode, weighted, a.n_frames, a.npix))) {
         // register-resident fast kernel; pixels it cannot decide go to the exact kernel
         nl::FastArgs f;
         f.fb_list = h->d_fb_list;

@@ -588,9 +588,9 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
     }
 }
 
-int fast_supported(int mode, bool weighted, int n_frames)
+int fast_supported(int mode, bool weighted, int n_frames, int64_t npix)
 {
-    if (n_frames < 2 || n_frames > 128) return 0;
+    if (n_frames < 2 || n_frames > 128 || npix >= kFastMaxPixels) return 0;
     if (mode == NL_ST_MEDIAN) return 1;
     return ((mode == NL_ST_SIGMA || mode == NL_ST_WINSOR_SIGMA) && !weighted) ? 1 : 0;
 }
@@ -651,9 +651,9 @@ static void launch_mad(const StackArgs &args, const FastArgs &f, unsigned blocks
     hipLaunchKernelGGL(stack_mad_fast_kernel<NS>, dim3(blocks), dim3(256), 0, stream, args, f);
 }
 
-int mad_fast_supported(int mode, bool weighted, int n_frames)
+int mad_fast_supported(int mode, bool weighted, int n_frames, int64_t npix)
 {
-    return (mode == NL_ST_MAD_SIGMA && !weighted && n_frames >= 1 && n_frames <= 128) ? 1 : 0;
+    return (mode == NL_ST_MAD_SIGMA && !weighted && n_frames >= 1 && n_frames <= 128 && npix < kFastMaxPixels) ? 1 : 0;
 }
 
 hipError_t launch_stack_mad_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name)

@@ -54,11 +54,14 @@ hipError_t launch_reduce_counters(const unsigned long long *partial, int n_block
                                   unsigned long long *counters, hipStream_t stream);
 
 // ---- stack_fast.hip ----
-int fast_supported(int mode, bool weighted, int n_frames);
+// one-lane register kernels address a group of 4 frames through one buffer descriptor with
+// 32-bit offsets (3 frames + the pixel): tiles of 2^27 pixels or more take the int64-indexed kernels
+constexpr int64_t kFastMaxPixels = (int64_t)1 << 27;
+int fast_supported(int mode, bool weighted, int n_frames, int64_t npix);
 hipError_t launch_stack_median_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
                                     const char **name, hipEvent_t dominant_done);
 // dominant_done (optional) is recorded right after the first, dominant kernel
-int mad_fast_supported(int mode, bool weighted, int n_frames);
+int mad_fast_supported(int mode, bool weighted, int n_frames, int64_t npix);
 hipError_t launch_stack_mad_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name);
 // after_dominant(user) is called between the launch of the dominant (zonal) kernel and
 // the generic pass, so the caller can start work that only depends on the former
@@ -91,7 +94,7 @@ struct LinfitCascade {
     unsigned capacity;
 };
 constexpr int kLinfitStages = 4;
-int linfit_fast_supported(int mode, int n_frames);
+int linfit_fast_supported(int mode, int n_frames, int64_t npix);
 int linfit_ml_supported(int mode, int n_frames, int64_t npix);
 
 hipError_t launch_stack_linfit_fast(const StackArgs &args, const FastArgs &fargs, const LinfitCascade *cascade,

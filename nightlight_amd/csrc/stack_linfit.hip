@@ -529,9 +529,9 @@ hipError_t launch_stack_linfit_ml(const StackArgs &args, const FastArgs &fargs, 
     return hipGetLastError();
 }
 
-int linfit_fast_supported(int mode, int n_frames)
+int linfit_fast_supported(int mode, int n_frames, int64_t npix)
 {
-    return (mode == NL_ST_LINEAR_FIT && n_frames >= 1 && n_frames <= 128) ? 1 : 0;
+    return (mode == NL_ST_LINEAR_FIT && n_frames >= 1 && n_frames <= 128 && npix < kFastMaxPixels) ? 1 : 0;
 }
 
 template <int NS>

@@ -77,6 +77,13 @@ class StackHandle:
         capi.check(self._lib.nl_stack_download_tile(self._h, int(idx), capi.fptr(out)))
         return out
 
+    def download_rows(self, idx, first_row, n_rows):
+        """Rows [first_row, first_row+n_rows) (tile-relative) of frame idx; idx=-1: of the result."""
+        out = np.empty(int(n_rows) * self.width, np.float32)
+        capi.check(self._lib.nl_stack_download_rows(self._h, int(idx), int(first_row), int(n_rows),
+                                                    capi.fptr(out)))
+        return out
+
     def fill_synthetic(self, seed=0x4E4C5354):
         capi.check(self._lib.nl_stack_fill_synthetic(self._h, C.c_uint64(seed)))
 

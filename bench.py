@@ -4,20 +4,30 @@
 One "step" = one full stack pass (OpStack.Apply's numeric core,
 internal/ops/stack/stack.go:142-218) over a synthetic sub-exposure stack that
 is already resident in HBM.  Default workload = BASELINE.json configs[1]:
-128 x 4096 x 4096 fp32 frames, sigma-clipped mean, kappa = 3, one GPU.
+128 x 4096 x 4096 fp32 frames, sigma-clipped mean, kappa = 3.
 
-With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank
-owns one row tile of the same size (weak scaling: the image grows with N); the
-only exchange is the all-reduce of the two clip counters per pass (RCCL).
+--gpus N: one rank per GPU (launched by torch.distributed.run; when WORLD_SIZE
+is not set this script re-executes itself under it).  STRONG scaling, as
+BASELINE.json's metric asks: the image stays 4096 x 4096 and rank g owns the
+rows tile_rows(4096, N, g) of all frames (stack.go:142-152 split by pixel
+range).  The only exchange is the sum of the two clip counters per pass
+(stack.go:193-198): a 16-byte RCCL all-reduce on the device -- the counters are
+copied device-to-device behind the pass and reduced on the handle's own stream,
+no host round trip per pass.  --weak keeps the tile per GPU fixed instead.
 
 Prints ONE JSON line on rank 0 (contract in the task description) including
-  roofline     algorithmic HBM bytes (4*P*(N+1)) / HIP-event kernel time
-  cpu_baseline the CPU oracle (C restatement of the Go reference) timed on a
-               bounded strip of the same stack with all host cores.
+  roofline     algorithmic HBM bytes of one launch (4*tile_pixels*(N+1)) / the
+               dominant kernel's mean duration over the TIMED passes (HIP events
+               on the stream the kernel runs on, read back after the timed region)
+  cpu_baseline the CPU oracle (C restatement of the Go reference) on a bounded
+               strip of the same stack: 1 warm-up + median of 3, N separately
+               allocated host frames, all host threads.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +37,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MODE_NAMES = {0: "median", 1: "mean", 2: "sigma-clip", 3: "winsorized sigma-clip",
               4: "MAD sigma-clip", 5: "linear-fit"}
+TRAFFIC_FILES = ("r02_traffic.json", "r01_traffic.json")
 
 
 def parse():
@@ -36,11 +47,18 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=128)
     ap.add_argument("--width", type=int, default=4096)
-    ap.add_argument("--height", type=int, default=4096, help="rows per GPU")
+    ap.add_argument("--height", type=int, default=4096,
+                    help="image rows (strong scaling: split over the GPUs; --weak: rows per GPU)")
     ap.add_argument("--mode", type=int, default=2)
     ap.add_argument("--kappa", type=float, default=3.0)
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling: every rank owns a --height rows tile, the image grows with --gpus")
+    ap.add_argument("--row0", type=int, default=0,
+                    help="1-GPU runs only: first image row of the tile (with --image-height: one GPU's share of a larger image)")
+    ap.add_argument("--image-height", type=int, default=0,
+                    help="1-GPU runs only: height of the whole image the --height rows tile is cut from")
     ap.add_argument("--cpu-rows", type=int, default=0,
-                    help="rows of the stack timed on the CPU (0 = auto, about 10-30 s)")
+                    help="rows of the stack timed on the CPU (0 = auto, about 3 s per run)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--weighted", action="store_true",
                     help="per-frame weights in [0.2, 1] (the shape of inverse-noise weights, stack.go:246-253)")
@@ -51,68 +69,104 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_model():
+def cpu_info():
+    """(model name, hardware threads, physical cores) of the host."""
+    model, pairs, threads = "unknown CPU", set(), 0
     try:
+        phys = core = None
         for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
+            if line.startswith("model name") and model == "unknown CPU":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("processor"):
+                threads += 1
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+                pairs.add((phys, core))
     except OSError:
         pass
-    return "unknown CPU"
+    threads = threads or (os.cpu_count() or 1)
+    return model, threads, (len(pairs) or threads)
 
 
 def cpu_baseline(st, args, rows, weights=None):
-    """Times the oracle (oracle/nl_oracle.c, a C restatement of the Go reference:
-    same batching rule, one worker per host core) on the first `rows` rows."""
+    """Times the oracle (oracle/nl_oracle.c, a C restatement of the Go reference: same
+    batching rule stack.go:134-138, one worker per host thread) on the first `rows` rows:
+    frames as N separate host allocations (as fits.Image.Data is), 1 warm-up, median of 3."""
     import numpy as np
     from oracle import oracle
     n, w = args.frames, args.width
-    frames = np.empty((n, rows * w), np.float32)
-    for i in range(n):
-        frames[i] = st.download_tile(i)[: rows * w]
-    cores = os.cpu_count() or 1
-    t0 = time.perf_counter()
+    frames = [st.download_rows(i, 0, rows).copy() for i in range(n)]      # N separate allocations
+    model, threads, physical = cpu_info()
     ow = None if args.mode in (0, 5) else weights          # median / linear fit take no weights (stack.go:158,188)
-    rc, res, cl, ch, _ = oracle.stack_apply(args.mode, frames, ow, args.kappa, args.kappa,
-                                            0.0, num_cpu=cores)
-    dt = time.perf_counter() - t0
-    assert rc == 0
-    return {"value": round(rows * w / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores,
+    times = []
+    for it in range(4):
+        t0 = time.perf_counter()
+        rc, res, cl, ch, _ = oracle.stack_apply(args.mode, frames, ow, args.kappa, args.kappa,
+                                                0.0, num_cpu=threads)
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        if it > 0:
+            times.append(dt)
+    dt = sorted(times)[1]
+    return {"value": round(rows * w / dt / 1e6, 3), "unit": "Mpixels/s", "cores": threads,
+            "hardware_threads": threads, "physical_cores": physical,
             "kind": "port",
-            "sample": "first %d rows x %d px x %d frames of the same synthetic stack, %s, "
-                      "C restatement of the Go reference (no Go toolchain), %.1f s on %d threads of %s"
-                      % (rows, w, n, MODE_NAMES[args.mode], dt, cores, cpu_model())}, res, (cl, ch)
+            "sample": "first %d rows x %d px x %d frames of the same synthetic stack (N separate host "
+                      "allocations), %s, C restatement of the Go reference (no Go toolchain), 1 warm-up + "
+                      "median of 3 runs: %.2f s on %d threads (%d physical cores) of %s"
+                      % (rows, w, n, MODE_NAMES[args.mode], dt, threads, physical, model)}, res, (cl, ch)
 
 
-def measured_traffic(kernel, args):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes
-    (profiles/r01_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction),
-    or None when this workload was not profiled."""
-    try:
-        doc = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-    except Exception:
-        return None
-    for e in doc.get("entries", []):
-        if (e["kernel"] == kernel and e["frames"] == args.frames and e["width"] == args.width
-                and e["rows"] == args.height and e["mode"] == args.mode):
-            return e["traffic_bytes"]
-    return None
+def measured_traffic(kernel, args, rows):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this command
+    (profiles/rNN_traffic.json: FETCH_SIZE / WRITE_SIZE with the guide's gfx950
+    corrections), or (None, None) when this workload was not profiled."""
+    for name in TRAFFIC_FILES:
+        try:
+            doc = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        for e in doc.get("entries", []):
+            if (e["kernel"] == kernel and e["frames"] == args.frames and e["width"] == args.width
+                    and e["rows"] == rows and e["mode"] == args.mode):
+                return e["traffic_bytes"], "profiles/%s (separate rocprofv3 --pmc passes of this command)" % name
+    return None, None
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         args.gpus = world
 
     import numpy as np
     import torch
     from nightlight_amd import StackHandle
+    from nightlight_amd.dist import tile_rows
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if world > 1 and not args.share_device and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (world, torch.cuda.device_count()))
     device = 0 if args.share_device else local_rank
     torch.cuda.set_device(device)
     dist = None
@@ -122,94 +176,131 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend=args.backend)
-    comm_device = "cuda" if args.backend == "nccl" else "cpu"
+    on_device = args.backend == "nccl"
 
-    n, w, rows = args.frames, args.width, args.height
-    total_rows = rows * world
-    st = StackHandle(n, w, total_rows, row0=rank * rows, rows=rows, device=device)
+    n, w = args.frames, args.width
+    if args.weak:
+        image_rows = args.height * world
+        row0, rows = rank * args.height, args.height
+    elif world == 1 and args.image_height:
+        image_rows, row0, rows = args.image_height, args.row0, args.height
+    else:
+        image_rows = args.height
+        row0, rows = tile_rows(image_rows, world, rank)
+    st = StackHandle(n, w, image_rows, row0=row0, rows=rows, device=device)
     st.fill_synthetic()
     weights = None
     if args.weighted:
         weights = np.array([0.2 + 0.8 * ((k * 37) % 101) / 100.0 for k in range(n)], np.float32)
         st.set_weights(weights)
-    counters = torch.zeros(2, dtype=torch.int64, device=comm_device)
+
+    # global clip totals (the log line of stack.go:214-218 needs them on every pass)
+    totals = torch.zeros(2, dtype=torch.int64, device="cuda" if on_device else "cpu")
+    stream = torch.cuda.ExternalStream(st.stream_ptr, device=device) if (dist is not None and on_device) else None
+    pending = [None]
 
     def step():
         st.run_async(args.mode, args.kappa, args.kappa, 0.0)
-        cl, ch = st.finish()
-        if dist is not None:     # global clip totals, as the log line of stack.go:214-218 needs
-            counters.copy_(torch.tensor([cl, ch], dtype=torch.int64))
-            dist.all_reduce(counters)
-        return cl, ch
+        if dist is None:
+            return
+        if on_device:
+            # device-side reduction on the handle's own stream; the all-reduce of pass i overlaps pass i+1
+            with torch.cuda.stream(stream):
+                if pending[0] is not None:
+                    pending[0].wait()
+                st.copy_counters_async(totals.data_ptr())
+                pending[0] = dist.all_reduce(totals, async_op=True)
+        else:                                   # gloo rehearsal: counters through the host
+            cl, ch = st.finish()
+            totals.copy_(torch.tensor([cl, ch], dtype=torch.int64))
+            dist.all_reduce(totals)
 
     def fence():
+        if pending[0] is not None:
+            with torch.cuda.stream(stream):
+                pending[0].wait()
+            pending[0] = None
+        st.finish()
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    kernel_ms, pass_ms = [], []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        cl, ch = step()
-        kernel_ms.append(st.last_dominant_kernel_ms)     # HIP events around the dominant kernel
-        pass_ms.append(st.last_kernel_ms)                # ... and around every kernel of the pass
+        step()
     fence()
     dt = time.perf_counter() - t0
 
+    # HIP-event times of the timed passes, read back from the handle's ring after the fact
+    timed = min(args.steps, 64)
+    times = [st.pass_times(b) for b in range(timed)]
+    pass_ms = float(np.mean([t[0] for t in times]))
+    k_ms = float(np.mean([t[1] for t in times]))
+    cl, ch = st.finish()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=comm_device)
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_device else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        cl, ch = int(totals[0].item()), int(totals[1].item())
 
     if rank == 0:
-        pixels_per_step = rows * w * world
+        pixels_per_step = image_rows * w
         ms_per_step = dt * 1e3 / args.steps
         value = pixels_per_step * args.steps / dt / 1e6
-        k_ms = float(np.mean(kernel_ms))
-        alg_bytes = 4.0 * rows * w * (n + 1)          # per launch (one tile), SURVEY 8d
+        alg_bytes = 4.0 * rows * w * (n + 1)          # per launch (rank 0's tile), SURVEY 8d
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic, traffic_source = measured_traffic(st.last_kernel_name, args, rows)
+        if args.weak:
+            workload = "%d x %dx%d fp32 frames per GPU (weak scaling), %s%s kappa=%g, frames resident in HBM" % (
+                n, rows, w, MODE_NAMES[args.mode], " (weighted)" if args.weighted else "", args.kappa)
+        else:
+            workload = "%d x %dx%d fp32 frames, %s%s kappa=%g, rows split over %d GPU(s), frames resident in HBM" % (
+                n, image_rows, w, MODE_NAMES[args.mode], " (weighted)" if args.weighted else "", args.kappa, world)
+            if world == 1 and rows != image_rows:
+                workload = "rows [%d,%d) of " % (row0, row0 + rows) + workload
         out = {
-            "metric": "stacked Mpixels/sec (%s, %dx%dx%d fp32)" % (MODE_NAMES[args.mode], n, rows, w),
+            "metric": "stacked Mpixels/sec (%s, %dx%dx%d fp32)" % (MODE_NAMES[args.mode], n, image_rows, w),
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%d x %dx%d fp32 frames per GPU, %s%s kappa=%g, frames resident in HBM"
-                                   % (n, rows, w, MODE_NAMES[args.mode], " (weighted)" if args.weighted else "",
-                                      args.kappa),
-                       "frames": n, "width": w, "rows_per_gpu": rows, "mode": args.mode,
-                       "sharding": "row tiles, %d rank(s); all-reduce of 2 int64 clip counters per pass" % world,
-                       "clip_low": int(counters[0].item()) if dist is not None else cl,
-                       "clip_high": int(counters[1].item()) if dist is not None else ch},
+            "config": {"workload": workload,
+                       "frames": n, "width": w, "image_rows": image_rows, "rows_per_gpu": rows, "mode": args.mode,
+                       "sharding": "row tiles, %d rank(s); per pass one all-reduce of 2 int64 clip counters%s"
+                                   % (world, " on the device (RCCL, the pass's own stream)" if (world > 1 and on_device)
+                                      else ""),
+                       "clip_low": cl, "clip_high": ch},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": measured_traffic(st.last_kernel_name, args),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": st.last_kernel_name,
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes": alg_bytes,
-                         "pass_ms": round(float(np.mean(pass_ms)), 4),
-                         "pass_frac": round(alg_bytes / (float(np.mean(pass_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "timed_passes_averaged": timed,
+                         "pass_ms": round(pass_ms, 4),
+                         "pass_frac": round(alg_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          "pixels_redone_by_exact_kernel": st.last_fallback_pixels},
         }
         if world == 1 and not args.no_cpu:
             cpu_rows = args.cpu_rows
             if cpu_rows <= 0:
-                # about 10-30 s of CPU time: the oracle does ~5e6 samples/s per core
-                # (sigma clip), so give every core ~12 s of work, capped at the tile
-                cores = os.cpu_count() or 1
-                cpu_rows = max(8, min(rows, int(cores * 12 * 5.0e6 / (n * w))))
+                # about 3 s per run (x4 runs): the oracle does ~5e6 samples/s per thread (sigma clip)
+                threads = os.cpu_count() or 1
+                cpu_rows = max(8, min(rows, int(threads * 3 * 5.0e6 / (n * w))))
             cpu_rows = min(cpu_rows, rows)
             base, res, cc = cpu_baseline(st, args, cpu_rows, weights)
             # parity in the same run: the same strip through the C ABI vs the oracle.
             # Clip counters must be equal; values within the north star's 1e-5
-            # (bit-exact for every kernel but the register-resident sigma one).
-            with StackHandle(n, w, total_rows, row0=0, rows=cpu_rows, device=device) as strip:
+            # (bit-exact for every kernel but the register-resident ones).
+            with StackHandle(n, w, image_rows, row0=row0, rows=cpu_rows, device=device) as strip:
                 strip.fill_synthetic()
                 strip.set_weights(weights)
-                got, gl, gh = strip.run(args.mode, args.kappa, args.kappa, 0.0)
-                got = got[: cpu_rows * w]
+                strip.run_async(args.mode, args.kappa, args.kappa, 0.0)
+                gl, gh = strip.finish()
+                got = strip.download_rows(-1, 0, cpu_rows)
             ok = ~np.isnan(res) & (res != 0)
             same_nan = bool(np.array_equal(np.isnan(got), np.isnan(res)))
             rel = float(np.max(np.abs(got[ok].astype(np.float64) - res[ok]) / np.abs(res[ok]))) if ok.any() else 0.0

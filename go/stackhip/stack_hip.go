@@ -25,18 +25,24 @@ import "C"
 import (
 	"errors"
 	"fmt"
+	"runtime"
 	"unsafe"
 
 	"github.com/mlnoga/nightlight/internal/fits"
 	"github.com/mlnoga/nightlight/internal/ops"
 )
 
-// Device selects the GPU this process stacks on (one process per GPU).
-var Device = 0
+// Devices lists the GPUs this process stacks on: every stack is split into one row tile per
+// entry (nl_group_*, the same pixel-range split the reference makes over goroutines,
+// stack.go:142-152), the clip counters are summed on the host.  nil = all visible GPUs.
+var Devices []int
 
+// lastError reads the calling OS thread's message.  nl_last_error() is thread-local and a
+// goroutine may migrate between the failing cgo call and this one, so every call+error pair
+// runs under runtime.LockOSThread (see Apply).
 func lastError() error { return errors.New(C.GoString(C.nl_last_error())) }
 
-// Apply stacks a set of light frames on the GPU.  Same contract as
+// Apply stacks a set of light frames on the GPUs.  Same contract as
 // internal/ops/stack/stack.go:115-227: mode validation and auto selection,
 // weights from getWeights (kept in Go, stack.go:231-270), one result image with
 // the summed exposure, the "Clipped low ..." log line from the counters.
@@ -59,20 +65,38 @@ func (op *OpStack) Apply(f []*fits.Image, c *ops.Context) (result *fits.Image, e
 		return nil, errors.New("MADSigma stacking with weights is still unimplemented") // reference panics, stack.go:185
 	}
 
+	// the reference indexes every frame with the first frame's length (stack.go:151) and would
+	// panic on a short one; the C side cannot see slice lengths, so check here
+	for _, l := range f {
+		if len(l.Data) != len(f[0].Data) {
+			return nil, fmt.Errorf("%d: frame has %d pixels, expected %d", l.ID, len(l.Data), len(f[0].Data))
+		}
+	}
+
+	runtime.LockOSThread() // nl_last_error() is per OS thread
+	defer runtime.UnlockOSThread()
+
 	width, height := int(f[0].Naxisn[0]), len(f[0].Data)/int(f[0].Naxisn[0])
-	h := C.nl_stack_create(C.int(len(f)), C.int(width), C.int(height), 0, C.int(height), C.int(Device))
-	if h == nil {
+	var devs *C.int
+	if len(Devices) > 0 {
+		cdev := make([]C.int, len(Devices))
+		for i, d := range Devices {
+			cdev[i] = C.int(d)
+		}
+		devs = &cdev[0]
+	}
+	g := C.nl_group_create(C.int(len(f)), C.int(width), C.int(height), C.int(len(Devices)), devs)
+	if g == nil {
 		return nil, lastError()
 	}
-	defer C.nl_stack_destroy(h)
+	defer C.nl_group_destroy(g)
 
-	// one cgo call per Go slice: [][]float32 cannot cross cgo, and the copy
-	// builds the planar [N][H*W] device layout on the way.  The asynchronous
-	// variant copies the slice into a pinned staging buffer before it returns
-	// (no Go pointer is retained) and lets the DMA of frame i overlap the
-	// staging of frame i+1; nl_stack_run waits for the uploads on the device.
+	// one cgo call per Go slice: [][]float32 cannot cross cgo, and the copy builds the planar
+	// [N][rows*W] layout of every device tile on the way.  Each tile copies its rows into its
+	// own pinned staging buffer before the call returns (no Go pointer is retained) and the
+	// DMA of frame i overlaps the staging of frame i+1; the pass waits for them on the device.
 	for i, l := range f {
-		if rc := C.nl_stack_upload_frame_async(h, C.int(i), (*C.float)(unsafe.Pointer(&l.Data[0]))); rc != C.NL_OK {
+		if rc := C.nl_group_upload_frame(g, C.int(i), (*C.float)(unsafe.Pointer(&l.Data[0]))); rc != C.NL_OK {
 			return nil, lastError()
 		}
 	}
@@ -80,13 +104,13 @@ func (op *OpStack) Apply(f []*fits.Image, c *ops.Context) (result *fits.Image, e
 	if weights != nil {
 		wp = (*C.float)(unsafe.Pointer(&weights[0]))
 	}
-	if rc := C.nl_stack_set_weights(h, wp); rc != C.NL_OK {
+	if rc := C.nl_group_set_weights(g, wp); rc != C.NL_OK {
 		return nil, lastError()
 	}
 
 	data := make([]float32, len(f[0].Data))
 	var clipLow, clipHigh C.int64_t
-	if rc := C.nl_stack_run(h, C.int(mode), C.float(op.SigmaLow), C.float(op.SigmaHigh), C.float(op.RefFrameLoc),
+	if rc := C.nl_group_run(g, C.int(mode), C.float(op.SigmaLow), C.float(op.SigmaHigh), C.float(op.RefFrameLoc),
 		(*C.float)(unsafe.Pointer(&data[0])), &clipLow, &clipHigh); rc != C.NL_OK {
 		return nil, lastError()
 	}

@@ -106,6 +106,11 @@ int nl_stack_download_tile(nl_stack_t *h, int idx, float *host_tile);
  * it lets a caller inspect parts of stacks far larger than host memory. */
 int nl_stack_download_rows(nl_stack_t *h, int idx, int first_row, int n_rows, float *host_rows);
 
+/* Frames in use by the next uploads / passes: slots [0, n), 1 <= n <= the n_frames given
+ * to nl_stack_create.  Lets a batch loop (OpStackBatches, stackbatches.go:69-111) keep one
+ * handle and its device accumulator across batches of different sizes.  Clears the weights
+ * when n changes. */
+int nl_stack_set_active_frames(nl_stack_t *h, int n);
 /* getWeights (stack.go:231-270).  weights: n_frames floats or NULL = none. */
 int nl_stack_set_weights(nl_stack_t *h, const float *weights);
 /* Computes the weights from per-frame scalars exactly as getWeights does:
@@ -138,6 +143,19 @@ float nl_stack_last_kernel_ms(nl_stack_t *h);
 /* Same, for the dominant kernel of the pass alone (the one named by
  * nl_stack_last_kernel_name); the difference is the hand-over passes. */
 float nl_stack_last_dominant_kernel_ms(nl_stack_t *h);
+/* GPU times of the pass enqueued `back` passes ago (0 = the last one): the handle keeps the
+ * HIP events of its last 64 passes, so a caller may queue passes back to back without a host
+ * sync and read every pass's kernel time afterwards.  Either output may be NULL. */
+int nl_stack_pass_times(nl_stack_t *h, int back, float *pass_ms, float *dominant_ms);
+/* The handle's hipStream_t (passes are enqueued on it) and the device address of the
+ * {clip_low, clip_high} totals of the last pass (2 x uint64, valid once the pass has run on that
+ * stream): a multi-process caller reduces them across ranks ON THE DEVICE -- e.g. RCCL
+ * ncclAllReduce on this stream -- instead of a host round trip per pass (stack.go:193-198). */
+void *nl_stack_stream(nl_stack_t *h);
+void *nl_stack_counters_device_ptr(nl_stack_t *h);
+/* Enqueues, behind the last pass on the handle's stream, a copy of those 16 bytes into a
+ * caller-owned device buffer (zeros for modes without counters). */
+int nl_stack_copy_counters_async(nl_stack_t *h, void *device_dst);
 /* on != 0: run every mode with the bit-exact kernels only (per-pixel replay
  * of the reference's permutation; slow, used for verification; 1 = one pixel
  * per lane with the column in LDS, 2 = one wavefront per pixel where that
@@ -157,13 +175,43 @@ const char *nl_stack_last_kernel_name(nl_stack_t *h);
  * pass the tile's {clip_low, clip_high} are handed to `reduce` (may be NULL
  * for a single tile) which must replace them with the totals over all tiles
  * -- e.g. an RCCL all-reduce -- so every rank takes the same branch.
- * total_samples = width*height*n_frames of the WHOLE image. */
+ * The percentages are taken of width*height*n_frames (the WHOLE image) when a
+ * reducer is given, of this handle's tile (rows*width*n_frames) when it is NULL. */
 typedef int (*nl_reduce_fn)(int64_t *counters2, void *user);
 int nl_stack_find_sigmas(nl_stack_t *h, int mode, float ref_loc,
                          float clip_perc_low, float clip_perc_high,
                          nl_reduce_fn reduce, void *user,
                          float *out_host, int64_t *clip_low, int64_t *clip_high,
                          float *sigma_low, float *sigma_high, int *passes);
+
+/* ---- one stack over several GPUs from ONE process (stack.go:142-152, 193-198) ----
+ * The reference's Apply splits the pixel range over goroutines and sums the two clip
+ * counters over them; nl_group_* is that split over the GPUs of the node for a
+ * single-process host (the Go CLI behind cgo, the C++ operator mirror): tile t owns the
+ * rows nl_group_tile_rows(height, n_tiles, t) of all frames on devices[t] (devices ==
+ * NULL: device t modulo the device count; n_tiles <= 0: one tile per device).  All
+ * tiles' passes are enqueued before any is awaited; result tiles land in disjoint rows
+ * of out_host; the counters are summed on the host.  Same arguments, error codes and
+ * messages as the nl_stack_* calls they fan out to. */
+typedef struct nl_group nl_group_t;
+void nl_group_tile_rows(int height, int n_tiles, int t, int *row0, int *rows);
+nl_group_t *nl_group_create(int n_frames, int width, int height, int n_tiles, const int *devices);
+void nl_group_destroy(nl_group_t *g);
+int nl_group_size(nl_group_t *g);
+nl_stack_t *nl_group_tile(nl_group_t *g, int t);            /* borrowed, owned by the group */
+int nl_group_upload_frame(nl_group_t *g, int idx, const float *host_frame);   /* overlapped, pointer not retained */
+int nl_group_fill_synthetic(nl_group_t *g, uint64_t seed);
+int nl_group_set_active_frames(nl_group_t *g, int n);
+int nl_group_set_weights(nl_group_t *g, const float *weights);
+int nl_group_set_exact(nl_group_t *g, int on);
+int nl_group_run(nl_group_t *g, int mode, float sigma_low, float sigma_high, float ref_loc,
+                 float *out_host, int64_t *clip_low, int64_t *clip_high);
+int nl_group_last_mode(nl_group_t *g);
+int nl_group_find_sigmas(nl_group_t *g, int mode, float ref_loc, float clip_perc_low, float clip_perc_high,
+                         float *out_host, int64_t *clip_low, int64_t *clip_high,
+                         float *sigma_low, float *sigma_high, int *passes);
+int nl_group_accumulate(nl_group_t *g, float weight, int first);
+int nl_group_accumulate_finalize(nl_group_t *g, float weight_sum, float *out_host);
 
 /* ---- stack of stacks (StackIncremental / Finalize, stack.go:924-944) ----
  * acc += result_of_last_pass * weight (first != 0: acc = result*weight),
@@ -238,19 +286,25 @@ int nl_host_op_stack_apply_json(const char *json, int n_frames, int width, int h
                                 const float *hfr, int device, int max_threads,
                                 float *out, float *exposure_out,
                                 char *log_buf, int log_cap, char *err_buf, int err_cap);
+/* Devices every host-side operator of this process stacks on from now on: one row tile of
+ * each stack per entry (nl_group_*); a device may repeat.  n <= 0: back to the `device`
+ * argument of the calls below. */
+int nl_host_set_devices(const int *devices, int n);
 /* Unmarshal with defaults (stack.go:92-99), marshal back. */
 const char *nl_host_op_stack_roundtrip_json(const char *json);
 /* OpStackBatches (internal/ops/stack/stackbatches.go:46-217): partition the inputs
  * into batches that fit stack_memory_mb (Context.StackMemoryMB, operator.go:41),
  * stack every batch with the per-batch "stack" operator given as JSON, combine
  * the batch results with StackIncremental / StackIncrementalFinalize weighted by
- * the batch frame counts (stack.go:924-944).  Same log lines and error strings;
- * the batch shuffle uses a fixed-seed generator instead of Go's math/rand. */
+ * the batch frame counts (stack.go:924-944) ON THE DEVICES (nl_group_accumulate).  Same log
+ * lines and error strings; the permutation comes from a fixed-seed generator instead of Go's
+ * math/rand and is sorted inside every batch as stackbatches.go:199-209 does.  perm_out
+ * (n_frames ints or NULL): input index of every position, batches = consecutive runs. */
 int nl_host_op_stack_batches_apply_json(const char *per_batch_json, int n_frames, int width,
                                         int height, const float *const *frames,
                                         const float *exposure, int device, int max_threads,
                                         int memory_mb, int stack_memory_mb, float *out,
-                                        float *exposure_out, char *log_buf, int log_cap,
+                                        float *exposure_out, int *perm_out, char *log_buf, int log_cap,
                                         char *err_buf, int err_cap);
 
 #ifdef __cplusplus

@@ -33,17 +33,21 @@ EXPORTS = [
     "nl_stack_create", "nl_stack_destroy",
     "nl_stack_upload_frame", "nl_stack_upload_tile", "nl_stack_upload_frame_async", "nl_stack_upload_wait", "nl_stack_frames_device_ptr",
     "nl_stack_attach_device_frames", "nl_stack_fill_synthetic", "nl_stack_download_tile", "nl_stack_download_rows",
-    "nl_stack_set_weights", "nl_weights_from_scalars",
+    "nl_stack_set_active_frames", "nl_stack_set_weights", "nl_weights_from_scalars",
     "nl_stack_run", "nl_stack_run_async", "nl_stack_finish", "nl_stack_result_device_ptr",
     "nl_stack_last_mode", "nl_stack_last_kernel_ms", "nl_stack_last_dominant_kernel_ms",
-    "nl_stack_last_kernel_name",
+    "nl_stack_last_kernel_name", "nl_stack_pass_times", "nl_stack_stream", "nl_stack_counters_device_ptr", "nl_stack_copy_counters_async",
+    "nl_group_tile_rows", "nl_group_create", "nl_group_destroy", "nl_group_size", "nl_group_tile",
+    "nl_group_upload_frame", "nl_group_fill_synthetic", "nl_group_set_active_frames", "nl_group_set_weights", "nl_group_set_exact",
+    "nl_group_run", "nl_group_last_mode", "nl_group_find_sigmas", "nl_group_accumulate",
+    "nl_group_accumulate_finalize",
     "nl_stack_set_exact", "nl_stack_last_fallback_pixels",
     "nl_stack_find_sigmas", "nl_stack_accumulate", "nl_stack_accumulate_finalize",
     "nl_stack_frame_stats", "nl_stack_frame_noise", "nl_stack_weights_from_noise",
     "nl_median_filter_3x3",
     "nl_stack_upload_frame_fits", "nl_stack_upload_frame_projected", "nl_stack_frame_affine",
     "nl_stack_download_result_fits", "nl_fits_decode", "nl_project_bilinear",
-    "nl_host_op_stack_apply_json", "nl_host_op_stack_roundtrip_json",
+    "nl_host_op_stack_apply_json", "nl_host_op_stack_roundtrip_json", "nl_host_set_devices",
     "nl_host_op_stack_batches_apply_json",
 ]
 
@@ -93,6 +97,8 @@ def load():
     L.nl_stack_attach_device_frames.argtypes = [vp, vp]
     L.nl_stack_fill_synthetic.argtypes = [vp, C.c_uint64]
     L.nl_stack_set_weights.argtypes = [vp, _f32p]
+    L.nl_stack_set_active_frames.argtypes = [vp, C.c_int]
+    L.nl_group_set_active_frames.argtypes = [vp, C.c_int]
     L.nl_weights_from_scalars.argtypes = [C.c_int, _f32p, C.c_int, _f32p, _intp]
     L.nl_stack_run.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, _f32p, _i64p, _i64p]
     L.nl_stack_run_async.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float]
@@ -107,6 +113,31 @@ def load():
     L.nl_stack_last_kernel_name.argtypes = [vp]
     L.nl_stack_last_kernel_name.restype = C.c_char_p
     L.nl_stack_set_exact.argtypes = [vp, C.c_int]
+    L.nl_stack_pass_times.argtypes = [vp, C.c_int, _f32p, _f32p]
+    L.nl_stack_stream.argtypes = [vp]
+    L.nl_stack_stream.restype = vp
+    L.nl_stack_counters_device_ptr.argtypes = [vp]
+    L.nl_stack_counters_device_ptr.restype = vp
+    L.nl_stack_copy_counters_async.argtypes = [vp, vp]
+    L.nl_group_tile_rows.argtypes = [C.c_int, C.c_int, C.c_int, _intp, _intp]
+    L.nl_group_tile_rows.restype = None
+    L.nl_group_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _intp]
+    L.nl_group_create.restype = vp
+    L.nl_group_destroy.argtypes = [vp]
+    L.nl_group_destroy.restype = None
+    L.nl_group_size.argtypes = [vp]
+    L.nl_group_tile.argtypes = [vp, C.c_int]
+    L.nl_group_tile.restype = vp
+    L.nl_group_upload_frame.argtypes = [vp, C.c_int, _f32p]
+    L.nl_group_fill_synthetic.argtypes = [vp, C.c_uint64]
+    L.nl_group_set_weights.argtypes = [vp, _f32p]
+    L.nl_group_set_exact.argtypes = [vp, C.c_int]
+    L.nl_group_run.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, _f32p, _i64p, _i64p]
+    L.nl_group_last_mode.argtypes = [vp]
+    L.nl_group_find_sigmas.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, _f32p, _i64p, _i64p,
+                                       _f32p, _f32p, _intp]
+    L.nl_group_accumulate.argtypes = [vp, C.c_float, C.c_int]
+    L.nl_group_accumulate_finalize.argtypes = [vp, C.c_float, _f32p]
     L.nl_stack_last_fallback_pixels.argtypes = [vp]
     L.nl_stack_last_fallback_pixels.restype = C.c_int64
     L.nl_stack_find_sigmas.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, REDUCE_FN,
@@ -133,7 +164,8 @@ def load():
                                               _f32p, _f32p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
     L.nl_host_op_stack_batches_apply_json.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_f32p),
                                                       _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p,
-                                                      C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+                                                      _intp, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    L.nl_host_set_devices.argtypes = [_intp, C.c_int]
     L.nl_host_op_stack_roundtrip_json.argtypes = [C.c_char_p]
     L.nl_host_op_stack_roundtrip_json.restype = C.c_char_p
     _lib = L

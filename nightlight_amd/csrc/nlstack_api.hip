@@ -38,6 +38,7 @@ int fail(int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                \
     } while (0)
 
+constexpr int kTimingRing = 64;     // passes whose HIP-event times can be read back after the fact
 constexpr int kStageSlots = 4;      // pinned staging buffers of the asynchronous upload
 constexpr int kStageThreads = 4;    // host threads filling one staging buffer
 constexpr int kStatBlocks = 2048;
@@ -59,10 +60,17 @@ int next_pow2(int n)
 struct nl_stack {
     int device = 0;
     int n_frames = 0, width = 0, height = 0, row0 = 0, rows = 0;
+    int n_capacity = 0;               // frame slots allocated; n_frames <= n_capacity are in use (nl_stack_set_active_frames)
     int64_t npix = 0;                 // rows*width
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;      // whole pass
-    hipEvent_t ev_dom0 = nullptr, ev_dom1 = nullptr;        // dominant kernel only
+    // HIP events of the last kTimingRing passes (whole pass; dominant kernel only), so a caller can
+    // queue many passes without a host sync and read every pass's GPU time afterwards
+    hipEvent_t ring_start[kTimingRing] = {}, ring_stop[kTimingRing] = {};
+    hipEvent_t ring_dom0[kTimingRing] = {}, ring_dom1[kTimingRing] = {};
+    int64_t pass_seq = 0;                                  // passes enqueued so far
+    int64_t copy_waits_pass = 0;                           // pass the copy stream has been ordered behind
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;      // = the ring slot of the current / last pass
+    hipEvent_t ev_dom0 = nullptr, ev_dom1 = nullptr;
     hipStream_t side_stream = nullptr;                     // replay of the dominant kernel's hand-overs,
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;        // concurrent with the generic pass
     float *d_frames_owned = nullptr;  // [n_frames][npix]
@@ -119,6 +127,10 @@ int nl_device_count(void)
 static int destroy_impl(nl_stack_t *h)
 {
     if (!h) return NL_OK;
+    if (!h->stream) {             // create failed before anything existed on a device (e.g. a bad ordinal):
+        delete h;                 // no HIP call, so no stale error is left behind for hipGetLastError
+        return NL_OK;
+    }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->d_frames_owned) (void)hipFree(h->d_frames_owned);
@@ -143,10 +155,12 @@ static int destroy_impl(nl_stack_t *h)
         if (h->stage_done[i]) (void)hipEventDestroy(h->stage_done[i]);
     }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
-    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
-    if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
-    if (h->ev_dom0) (void)hipEventDestroy(h->ev_dom0);
-    if (h->ev_dom1) (void)hipEventDestroy(h->ev_dom1);
+    for (int i = 0; i < kTimingRing; i++) {
+        if (h->ring_start[i]) (void)hipEventDestroy(h->ring_start[i]);
+        if (h->ring_stop[i]) (void)hipEventDestroy(h->ring_stop[i]);
+        if (h->ring_dom0[i]) (void)hipEventDestroy(h->ring_dom0[i]);
+        if (h->ring_dom1[i]) (void)hipEventDestroy(h->ring_dom1[i]);
+    }
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -169,10 +183,14 @@ static int create_impl(nl_stack_t *h)
         return fail(NL_ERR_INVALID_ARG, "device %d out of range (have %d)", h->device, ndev);
     NL_HIP(hipSetDevice(h->device));
     NL_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    NL_HIP(hipEventCreate(&h->ev_start));
-    NL_HIP(hipEventCreate(&h->ev_stop));
-    NL_HIP(hipEventCreate(&h->ev_dom0));
-    NL_HIP(hipEventCreate(&h->ev_dom1));
+    for (int i = 0; i < kTimingRing; i++) {
+        NL_HIP(hipEventCreate(&h->ring_start[i]));
+        NL_HIP(hipEventCreate(&h->ring_stop[i]));
+        NL_HIP(hipEventCreate(&h->ring_dom0[i]));
+        NL_HIP(hipEventCreate(&h->ring_dom1[i]));
+    }
+    h->ev_start = h->ring_start[0]; h->ev_stop = h->ring_stop[0];
+    h->ev_dom0 = h->ring_dom0[0]; h->ev_dom1 = h->ring_dom1[0];
     NL_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     NL_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     NL_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -223,7 +241,7 @@ nl_stack_t *nl_stack_create(int n_frames, int width, int height, int row0, int r
         return nullptr;
     }
     nl_stack_t *h = new nl_stack();
-    h->device = device; h->n_frames = n_frames; h->width = width; h->height = height;
+    h->device = device; h->n_frames = h->n_capacity = n_frames; h->width = width; h->height = height;
     h->row0 = row0; h->rows = rows; h->npix = (int64_t)rows * width;
     if (create_impl(h) != NL_OK) {
         std::string keep = g_err;
@@ -283,6 +301,12 @@ int nl_stack_upload_frame_async(nl_stack_t *h, int idx, const float *host_frame)
         return fail(NL_ERR_INVALID_ARG, "upload_frame_async: frames are attached, not owned");
     const size_t bytes = (size_t)h->npix * sizeof(float);
     if (!h->copy_stream) NL_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (h->pass_seq > 0 && h->copy_waits_pass != h->pass_seq) {
+        // a pass enqueued earlier may still be reading the frames: the copy stream waits for its
+        // end on the device (staging batch b+1 while batch b is stacked must not overwrite b)
+        NL_HIP(hipStreamWaitEvent(h->copy_stream, h->ev_stop, 0));
+        h->copy_waits_pass = h->pass_seq;
+    }
     const int slot = h->stage_next;
     h->stage_next = (slot + 1) % kStageSlots;
     if (!h->h_stage[slot]) {
@@ -367,6 +391,19 @@ int nl_stack_fill_synthetic(nl_stack_t *h, uint64_t seed)
     return NL_OK;
 }
 
+// Frames in use for the next passes: slots [0, n) of the n_capacity allocated at create.  The
+// caller of a batch loop (OpStackBatches, stackbatches.go:69-111) keeps ONE handle -- buffers,
+// accumulator -- across batches whose last one is smaller.
+int nl_stack_set_active_frames(nl_stack_t *h, int n)
+{
+    NL_CHECK_HANDLE(h);
+    if (n < 1 || n > h->n_capacity)
+        return fail(NL_ERR_INVALID_ARG, "set_active_frames: %d not in [1, %d]", n, h->n_capacity);
+    if (n != h->n_frames) h->has_weights = false;      // weights are per frame of a given batch
+    h->n_frames = n;
+    return NL_OK;
+}
+
 int nl_stack_set_weights(nl_stack_t *h, const float *weights)
 {
     NL_CHECK_HANDLE(h);
@@ -423,6 +460,8 @@ int nl_weights_from_scalars(int weighting, const float *per_frame, int n_frames,
 static const nl::LinfitCascade *linfit_cascade(nl_stack_t *h, int lanes_per_pixel, nl::LinfitCascade *out)
 {
     if (!h->lf_tried) {
+        // sized for the most lanes per pixel any active frame count of this handle can need
+        lanes_per_pixel = h->n_capacity <= 128 ? 1 : h->n_capacity <= 256 ? 2 : 4;
         h->lf_tried = true;
         const size_t np = (size_t)h->npix;
         bool ok = hipMalloc(&h->d_lf_count, sizeof(unsigned) * nl::kLinfitStages) == hipSuccess;
@@ -488,6 +527,11 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
     a.list_capacity = 0;
     a.list_begin = nullptr;
 
+    {
+        const int slot = (int)(h->pass_seq % kTimingRing);
+        h->ev_start = h->ring_start[slot]; h->ev_stop = h->ring_stop[slot];
+        h->ev_dom0 = h->ring_dom0[slot]; h->ev_dom1 = h->ring_dom1[slot];
+    }
     NL_HIP(hipEventRecord(h->ev_start, h->stream));
     NL_HIP(hipMemsetAsync(h->d_partial, 0, kScratchBytes, h->stream));
     NL_HIP(hipEventRecord(h->ev_dom0, h->stream));
@@ -681,6 +725,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         h->last_has_counters = (mode != NL_ST_MEDIAN);
     }
     NL_HIP(hipEventRecord(h->ev_stop, h->stream));
+    h->pass_seq++;
     h->last_mode = mode;
     h->pending = true;
     return NL_OK;
@@ -738,6 +783,43 @@ int64_t nl_stack_last_fallback_pixels(nl_stack_t *h)
     return (int64_t)c;
 }
 
+// GPU times of a pass that is `back` passes old (0 = the last one enqueued); -1 where unavailable
+int nl_stack_pass_times(nl_stack_t *h, int back, float *pass_ms, float *dominant_ms)
+{
+    NL_CHECK_HANDLE(h);
+    if (back < 0 || back >= kTimingRing || (int64_t)back >= h->pass_seq)
+        return fail(NL_ERR_INVALID_ARG, "pass_times: pass %d back is not in the ring of %d", back, kTimingRing);
+    const int slot = (int)((h->pass_seq - 1 - back) % kTimingRing);
+    NL_HIP(hipEventSynchronize(h->ring_stop[slot]));
+    float ms = -1.0f;
+    if (pass_ms) {
+        NL_HIP(hipEventElapsedTime(&ms, h->ring_start[slot], h->ring_stop[slot]));
+        *pass_ms = ms;
+    }
+    if (dominant_ms) {
+        NL_HIP(hipEventElapsedTime(&ms, h->ring_dom0[slot], h->ring_dom1[slot]));
+        *dominant_ms = ms;
+    }
+    return NL_OK;
+}
+
+// enqueues, behind the last pass on the handle's stream, a 16-byte device-to-device copy of its
+// {clip_low, clip_high} totals into a caller-owned device buffer (e.g. the tensor an RCCL
+// all-reduce runs on): no host round trip between the pass and the reduction
+int nl_stack_copy_counters_async(nl_stack_t *h, void *device_dst)
+{
+    NL_CHECK_HANDLE(h);
+    if (!device_dst) return fail(NL_ERR_INVALID_ARG, "copy_counters_async: null destination");
+    if (h->last_has_counters)
+        NL_HIP(hipMemcpyAsync(device_dst, h->d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
+    else
+        NL_HIP(hipMemsetAsync(device_dst, 0, 2 * sizeof(unsigned long long), h->stream));
+    return NL_OK;
+}
+
+void *nl_stack_stream(nl_stack_t *h) { return h ? (void *)h->stream : nullptr; }
+void *nl_stack_counters_device_ptr(nl_stack_t *h) { return h ? (void *)h->d_counters : nullptr; }
+
 float nl_stack_last_kernel_ms(nl_stack_t *h)
 {
     if (!h || !h->ev_start) return -1.0f;
@@ -759,36 +841,30 @@ int nl_stack_find_sigmas(nl_stack_t *h, int mode, float ref_loc,
     if (mode == NL_ST_AUTO) mode = auto_select_mode(h->n_frames);
     if (mode != NL_ST_SIGMA && mode != NL_ST_WINSOR_SIGMA)
         return fail(NL_ERR_INVALID_MODE, "goal-seek bisection supports sigma and winsorized sigma only");
-    float low_left = 1.0f, low_right = 11.0f, low_mid = 0.5f * (low_left + low_right);
-    float high_left = 1.0f, high_right = 11.0f, high_mid = 0.5f * (high_left + high_right);
-    const float total = (float)((int64_t)h->width * h->height * (int64_t)h->n_frames);
+    // the counters cover the samples the percentages are taken of: with a reducer the whole
+    // image (every tile contributes), without one only this handle's tile
+    const int64_t total = reduce ? (int64_t)h->width * h->height * (int64_t)h->n_frames
+                                 : h->npix * (int64_t)h->n_frames;
+    nl::SigmaBisection bis(clip_perc_low, clip_perc_high, total);
     int n_pass = 0;
-    for (int i = 0;; i++) {
+    for (;;) {
         int64_t c[2] = {0, 0};
-        int rc = nl_stack_run(h, mode, low_mid, high_mid, ref_loc, nullptr, &c[0], &c[1]);
+        int rc = nl_stack_run(h, mode, bis.low_mid, bis.high_mid, ref_loc, nullptr, &c[0], &c[1]);
         if (rc != NL_OK) return rc;
         n_pass++;
         if (reduce) {
             rc = reduce(c, user);
             if (rc != 0) return fail(NL_ERR_INVALID_ARG, "counter reduction callback failed (%d)", rc);
         }
-        const float perc_l = (float)c[0] * 100.0f / total;
-        const float perc_h = (float)c[1] * 100.0f / total;
-        const int delta_l = (int)(100 * perc_l + 0.5f) - (int)(100 * clip_perc_low);
-        const int delta_h = (int)(100 * perc_h + 0.5f) - (int)(100 * clip_perc_high);
-        if ((delta_l == 0 && delta_h == 0) || i >= 20) {
+        if (bis.step(c[0], c[1])) {
             if (clip_low) *clip_low = c[0];
             if (clip_high) *clip_high = c[1];
-            if (sigma_low) *sigma_low = low_mid;
-            if (sigma_high) *sigma_high = high_mid;
+            if (sigma_low) *sigma_low = bis.low_mid;
+            if (sigma_high) *sigma_high = bis.high_mid;
             if (passes) *passes = n_pass;
             if (out_host) return nl_stack_finish(h, out_host, nullptr, nullptr);
             return NL_OK;
         }
-        if (delta_l > 0) { low_left = low_mid; low_mid = 0.5f * (low_left + low_right); }
-        else if (delta_l < 0) { low_right = low_mid; low_mid = 0.5f * (low_left + low_right); }
-        if (delta_h > 0) { high_left = high_mid; high_mid = 0.5f * (high_left + high_right); }
-        else if (delta_h < 0) { high_right = high_mid; high_mid = 0.5f * (high_left + high_right); }
     }
 }
 

@@ -1,0 +1,209 @@
+// nlstack_group.hip -- nl_group_*: one stack fanned out over several GPUs from ONE process.
+//
+// The reference's Apply splits the pixel range over goroutines
+// (internal/ops/stack/stack.go:142-152) and sums the two clip counters over them
+// (:193-198).  A single-process host -- the Go CLI behind the cgo shim, the C++
+// operator mirror -- gets the same split over the GPUs of the node here: tile t
+// owns the rows tile_rows(height, n_tiles, t) of ALL frames on its own device, the
+// passes of all tiles are enqueued before any is awaited, the result tiles land in
+// disjoint row ranges of the caller's buffer, and the counters are summed on the
+// host (two int64 per tile).  No pixel crosses devices, so there is no collective;
+// the multi-process form of the same split (torch.distributed / RCCL) is
+// nightlight_amd/dist.py.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+#include "stack_kernels.h"
+
+struct nl_group {
+    int n_frames = 0, width = 0, height = 0;
+    std::vector<nl_stack_t *> tiles;
+    std::vector<int> row0, rows;
+};
+
+extern "C" {
+
+void nl_group_tile_rows(int height, int n_tiles, int t, int *row0, int *rows)
+{
+    const int base = height / n_tiles, extra = height % n_tiles;
+    if (rows) *rows = base + (t < extra ? 1 : 0);
+    if (row0) *row0 = t * base + (t < extra ? t : extra);
+}
+
+void nl_group_destroy(nl_group_t *g)
+{
+    if (!g) return;
+    for (nl_stack_t *h : g->tiles) nl_stack_destroy(h);
+    delete g;
+}
+
+nl_group_t *nl_group_create(int n_frames, int width, int height, int n_tiles, const int *devices)
+{
+    int ndev = nl_device_count();
+    if (ndev <= 0) return nullptr;                       // nl_last_error: no HIP device, no CPU path
+    if (n_tiles <= 0) n_tiles = ndev;
+    if (n_tiles > height) n_tiles = height > 0 ? height : 1;
+    nl_group_t *g = new nl_group();
+    g->n_frames = n_frames; g->width = width; g->height = height;
+    for (int t = 0; t < n_tiles; t++) {
+        int r0 = 0, nr = 0;
+        nl_group_tile_rows(height, n_tiles, t, &r0, &nr);
+        nl_stack_t *h = nl_stack_create(n_frames, width, height, r0, nr, devices ? devices[t] : t % ndev);
+        if (!h) {
+            nl_group_destroy(g);                          // destroy never touches the thread's error message
+            return nullptr;
+        }
+        g->tiles.push_back(h);
+        g->row0.push_back(r0);
+        g->rows.push_back(nr);
+    }
+    return g;
+}
+
+int nl_group_size(nl_group_t *g) { return g ? (int)g->tiles.size() : 0; }
+
+nl_stack_t *nl_group_tile(nl_group_t *g, int t)
+{
+    return (g && t >= 0 && t < (int)g->tiles.size()) ? g->tiles[(size_t)t] : nullptr;
+}
+
+// every tile copies its rows out of the caller's frame into its own pinned staging buffer
+// (pointer not retained, cgo rules) and starts its DMA; nothing is awaited here
+int nl_group_upload_frame(nl_group_t *g, int idx, const float *host_frame)
+{
+    if (!g) return NL_ERR_INVALID_ARG;
+    for (size_t t = 0; t < g->tiles.size(); t++) {
+        int rc = nl_stack_upload_frame_async(g->tiles[t], idx, host_frame);
+        if (rc != NL_OK) return rc;
+    }
+    return NL_OK;
+}
+
+int nl_group_fill_synthetic(nl_group_t *g, uint64_t seed)
+{
+    if (!g) return NL_ERR_INVALID_ARG;
+    for (size_t t = 0; t < g->tiles.size(); t++) {
+        int rc = nl_stack_fill_synthetic(g->tiles[t], seed);
+        if (rc != NL_OK) return rc;
+    }
+    return NL_OK;
+}
+
+int nl_group_set_active_frames(nl_group_t *g, int n)
+{
+    if (!g) return NL_ERR_INVALID_ARG;
+    for (size_t t = 0; t < g->tiles.size(); t++) {
+        int rc = nl_stack_set_active_frames(g->tiles[t], n);
+        if (rc != NL_OK) return rc;
+    }
+    g->n_frames = n;
+    return NL_OK;
+}
+
+int nl_group_set_weights(nl_group_t *g, const float *weights)
+{
+    if (!g) return NL_ERR_INVALID_ARG;
+    for (size_t t = 0; t < g->tiles.size(); t++) {
+        int rc = nl_stack_set_weights(g->tiles[t], weights);
+        if (rc != NL_OK) return rc;
+    }
+    return NL_OK;
+}
+
+int nl_group_set_exact(nl_group_t *g, int on)
+{
+    if (!g) return NL_ERR_INVALID_ARG;
+    for (size_t t = 0; t < g->tiles.size(); t++) {
+        int rc = nl_stack_set_exact(g->tiles[t], on);
+        if (rc != NL_OK) return rc;
+    }
+    return NL_OK;
+}
+
+// stack.go:142-210 over the devices: enqueue every tile's pass, then collect
+int nl_group_run(nl_group_t *g, int mode, float sigma_low, float sigma_high, float ref_loc,
+                 float *out_host, int64_t *clip_low, int64_t *clip_high)
+{
+    if (!g) return NL_ERR_INVALID_ARG;
+    for (size_t t = 0; t < g->tiles.size(); t++) {
+        int rc = nl_stack_run_async(g->tiles[t], mode, sigma_low, sigma_high, ref_loc);
+        if (rc != NL_OK) return rc;
+    }
+    int64_t lo = 0, hi = 0;
+    for (size_t t = 0; t < g->tiles.size(); t++) {
+        int64_t l = 0, h = 0;
+        int rc = nl_stack_finish(g->tiles[t], out_host, &l, &h);
+        if (rc != NL_OK) return rc;
+        lo += l;                                          // stack.go:193-198
+        hi += h;
+    }
+    if (clip_low) *clip_low = lo;
+    if (clip_high) *clip_high = hi;
+    return NL_OK;
+}
+
+int nl_group_last_mode(nl_group_t *g) { return (g && !g->tiles.empty()) ? nl_stack_last_mode(g->tiles[0]) : -1; }
+
+// stackfindsigma.go:48-98 with the counters summed over the tiles after every pass
+int nl_group_find_sigmas(nl_group_t *g, int mode, float ref_loc, float clip_perc_low, float clip_perc_high,
+                         float *out_host, int64_t *clip_low, int64_t *clip_high,
+                         float *sigma_low, float *sigma_high, int *passes)
+{
+    if (!g || g->tiles.empty()) return NL_ERR_INVALID_ARG;
+    nl::SigmaBisection bis(clip_perc_low, clip_perc_high,
+                           (int64_t)g->width * g->height * (int64_t)g->n_frames);
+    int n_pass = 0;
+    for (;;) {
+        int64_t lo = 0, hi = 0;
+        int rc = nl_group_run(g, mode, bis.low_mid, bis.high_mid, ref_loc, nullptr, &lo, &hi);
+        if (rc != NL_OK) return rc;
+        if (n_pass == 0) {
+            const int m = nl_stack_last_mode(g->tiles[0]);
+            if (m != NL_ST_SIGMA && m != NL_ST_WINSOR_SIGMA) {
+                // same rule as nl_stack_find_sigmas; let it produce the message
+                return nl_stack_find_sigmas(g->tiles[0], mode, ref_loc, clip_perc_low, clip_perc_high, nullptr,
+                                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+            }
+        }
+        n_pass++;
+        if (bis.step(lo, hi)) {
+            if (clip_low) *clip_low = lo;
+            if (clip_high) *clip_high = hi;
+            if (sigma_low) *sigma_low = bis.low_mid;
+            if (sigma_high) *sigma_high = bis.high_mid;
+            if (passes) *passes = n_pass;
+            if (out_host)
+                for (size_t t = 0; t < g->tiles.size(); t++) {
+                    rc = nl_stack_finish(g->tiles[t], out_host, nullptr, nullptr);
+                    if (rc != NL_OK) return rc;
+                }
+            return NL_OK;
+        }
+    }
+}
+
+// StackIncremental / StackIncrementalFinalize (stack.go:924-944) on every tile's device
+int nl_group_accumulate(nl_group_t *g, float weight, int first)
+{
+    if (!g) return NL_ERR_INVALID_ARG;
+    for (size_t t = 0; t < g->tiles.size(); t++) {
+        int rc = nl_stack_accumulate(g->tiles[t], weight, first);
+        if (rc != NL_OK) return rc;
+    }
+    return NL_OK;
+}
+
+int nl_group_accumulate_finalize(nl_group_t *g, float weight_sum, float *out_host)
+{
+    if (!g) return NL_ERR_INVALID_ARG;
+    for (size_t t = 0; t < g->tiles.size(); t++) {
+        int rc = nl_stack_accumulate_finalize(g->tiles[t], weight_sum, out_host);
+        if (rc != NL_OK) return rc;
+    }
+    return NL_OK;
+}
+
+}  // extern "C"

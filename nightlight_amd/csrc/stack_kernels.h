@@ -44,6 +44,37 @@ struct FastArgs {
     unsigned in_capacity;
 };
 
+// Bisection of the goal-seek (spec: internal/ops/stack/stackfindsigma.go:48-98): sigma_low and
+// sigma_high in [1,11], percentages in the reference's fp32 arithmetic, 21 passes at most.
+// Host arithmetic shared by nl_stack_find_sigmas and nl_group_find_sigmas.
+struct SigmaBisection {
+    float low_left = 1.0f, low_right = 11.0f, low_mid;
+    float high_left = 1.0f, high_right = 11.0f, high_mid;
+    float perc_low, perc_high, total;
+    int i = 0;
+    SigmaBisection(float clip_perc_low, float clip_perc_high, int64_t total_samples)
+        : perc_low(clip_perc_low), perc_high(clip_perc_high), total((float)total_samples)
+    {
+        low_mid = 0.5f * (low_left + low_right);
+        high_mid = 0.5f * (high_left + high_right);
+    }
+    // counters of the pass run with (low_mid, high_mid); true = done, else the mids have moved
+    bool step(int64_t clip_low, int64_t clip_high)
+    {
+        const float pl = (float)clip_low * 100.0f / total;
+        const float ph = (float)clip_high * 100.0f / total;
+        const int delta_l = (int)(100 * pl + 0.5f) - (int)(100 * perc_low);
+        const int delta_h = (int)(100 * ph + 0.5f) - (int)(100 * perc_high);
+        if ((delta_l == 0 && delta_h == 0) || i >= 20) return true;
+        i++;
+        if (delta_l > 0) { low_left = low_mid; low_mid = 0.5f * (low_left + low_right); }
+        else if (delta_l < 0) { low_right = low_mid; low_mid = 0.5f * (low_left + low_right); }
+        if (delta_h > 0) { high_left = high_mid; high_mid = 0.5f * (high_left + high_right); }
+        else if (delta_h < 0) { high_right = high_mid; high_mid = 0.5f * (high_left + high_right); }
+        return false;
+    }
+};
+
 // ---- stack_exact.hip ----
 // Picks lanes-per-wave and LDS bytes for the exact kernel; -1 if it cannot fit.
 int exact_plan(int mode, bool weighted, int n_frames, int n_pad, int max_lanes, int *lanes,

@@ -236,6 +236,22 @@ static int autoSelectStackingMode(int l)   // stack.go:45-55
     return StMean;
 }
 
+// Devices the operator stacks on (not in the reference: its Apply fans out over goroutines,
+// stack.go:142-152; here the same pixel-range split goes over these GPUs through nl_group_*).
+// The Go shim has the same package variable.  A device may be listed more than once.
+static std::vector<int> &host_devices()
+{
+    static std::vector<int> d;
+    return d;
+}
+
+static std::vector<int> devices_for(const Context *c)
+{
+    if (c && !c->Devices.empty()) return c->Devices;
+    if (!host_devices().empty()) return host_devices();
+    return {c ? c->Device : 0};
+}
+
 // ---- stack.go:115-227 ------------------------------------------------------------------
 Result OpStack::Apply(const std::vector<ImagePtr> &f, Context *c)
 {
@@ -262,23 +278,30 @@ Result OpStack::Apply(const std::vector<ImagePtr> &f, Context *c)
     const std::vector<int32_t> &naxisn = f[0]->Naxisn;
     const int width = naxisn.empty() ? (int)f[0]->Data.size() : naxisn[0];
     const int height = width > 0 ? (int)(f[0]->Data.size() / (size_t)width) : 0;
-    nl_stack_t *h = nl_stack_create((int)f.size(), width, height, 0, height, c ? c->Device : 0);
+    // one group per Apply, or the caller's resident one (OpStackBatches keeps buffers and the
+    // stack-of-stacks accumulator on the devices across batches)
+    nl_group_t *h = Resident;
+    if (!h) {
+        const std::vector<int> devs = devices_for(c);
+        h = nl_group_create((int)f.size(), width, height, (int)devs.size(), devs.data());
+    }
     if (!h) return {nullptr, nl_last_error()};
     Result out;
     do {
-        int rc = NL_OK;
+        int rc = Resident ? nl_group_set_active_frames(h, (int)f.size()) : NL_OK;
         for (size_t i = 0; i < f.size() && rc == NL_OK; i++) {
             if (f[i]->Data.size() != f[0]->Data.size()) { out.err = "frames differ in size"; break; }
-            rc = nl_stack_upload_frame(h, (int)i, f[i]->Data.data());
+            rc = nl_group_upload_frame(h, (int)i, f[i]->Data.data());       // overlapped; pointer not retained
         }
         if (!out.err.empty()) break;
-        if (rc == NL_OK) rc = nl_stack_set_weights(h, weights.empty() ? nullptr : weights.data());
-        std::vector<float> data(f[0]->Data.size());
+        if (rc == NL_OK) rc = nl_group_set_weights(h, weights.empty() ? nullptr : weights.data());
+        // with a resident group the result stays on the devices (Data left empty)
+        std::vector<float> data(Resident ? 0 : f[0]->Data.size());
         int64_t clipLow = 0, clipHigh = 0;
-        if (rc == NL_OK) rc = nl_stack_run(h, mode, SigmaLow, SigmaHigh, RefFrameLoc, data.data(), &clipLow, &clipHigh);
+        if (rc == NL_OK) rc = nl_group_run(h, mode, SigmaLow, SigmaHigh, RefFrameLoc, Resident ? nullptr : data.data(), &clipLow, &clipHigh);
         if (rc != NL_OK) { out.err = nl_last_error(); break; }
         if (mode >= StSigma && c && c->Log) {          // stack.go:214-218
-            const float total = (float)((int64_t)data.size() * (int64_t)f.size());
+            const float total = (float)((int64_t)f[0]->Data.size() * (int64_t)f.size());
             char line[256];
             snprintf(line, sizeof line, "Clipped low %lld (%.2f%%) high %lld (%.2f%%)\n",
                      (long long)clipLow, (double)((float)clipLow * 100.0f / total),
@@ -287,10 +310,16 @@ Result OpStack::Apply(const std::vector<ImagePtr> &f, Context *c)
         }
         float exposureSum = 0;
         for (const auto &l : f) exposureSum += l->Exposure;
-        out.image = NewImageFromNaxisn(naxisn, std::move(data));
+        if (Resident) {
+            out.image = std::make_shared<Image>();            // metadata only; pixels are on the devices
+            out.image->Naxisn = naxisn;
+            out.image->Pixels = (int32_t)f[0]->Data.size();
+        } else {
+            out.image = NewImageFromNaxisn(naxisn, std::move(data));
+        }
         out.image->Exposure = exposureSum;
     } while (false);
-    nl_stack_destroy(h);
+    if (!Resident) nl_group_destroy(h);
     return out;
 }
 
@@ -386,14 +415,25 @@ bool OpStackBatches::partition(const std::vector<Promise> &ins, Context *c, std:
     if (c->Log) *c->Log << line;
 
     *insPerm = ins;
+    LastPerm.resize(ins.size());
+    for (size_t i = 0; i < ins.size(); i++) LastPerm[i] = (int)i;
     if (nb > 1) {                                                                               // :190-214
         if (c->Log) *c->Log << "Randomizing input files into batches...\n";
+        // rand.Perm: a uniformly random permutation of the indices (Go's global generator; here
+        // a fixed-seed Fisher-Yates, the batch membership is a free choice) ...
         uint64_t state = 0x9E3779B97F4A7C15ull;
-        for (size_t i = insPerm->size(); i > 1; i--) {
+        for (size_t i = LastPerm.size(); i > 1; i--) {
             state = state * 6364136223846793005ull + 1442695040888963407ull;
             const size_t j = (size_t)((state >> 33) % i);
-            std::swap((*insPerm)[i - 1], (*insPerm)[j]);
+            std::swap(LastPerm[i - 1], LastPerm[j]);
         }
+        // ... then sort.Ints inside every batch: frames keep their original relative order
+        // within a batch, which fixes every frame-order fp32 sum of the per-batch stack
+        for (int64_t i = 0; i < nb; i++) {
+            const int64_t from = i * bs, to = std::min<int64_t>((i + 1) * bs, (int64_t)LastPerm.size());
+            std::sort(LastPerm.begin() + from, LastPerm.begin() + to);
+        }
+        for (size_t i = 0; i < ins.size(); i++) (*insPerm)[i] = ins[(size_t)LastPerm[i]];
     }
     *numBatches = nb; *batchSize = bs; *maxThreads = mt;
     return true;
@@ -408,6 +448,25 @@ Result OpStackBatches::Apply(const std::vector<Promise> &ins, Context *c)
     c->MaxThreads = (int)maxThreads;                                                            // :62
     c->StatsTotal = (int)insPerm.size();
     c->StatsProcessed = 0;
+
+    // more than one batch: the frame buffers, the per-batch result and the stack of stacks stay on
+    // the devices (nl_group_accumulate = StackIncremental, stack.go:924-937); only the final
+    // image comes back.  The first frame sizes the group.
+    nl_group_t *resident = nullptr;
+    struct Guard {
+        nl_group_t **g; std::shared_ptr<OpStack> per;
+        ~Guard() { if (per) per->Resident = nullptr; if (*g) nl_group_destroy(*g); }
+    } guard{&resident, PerBatch};
+    if (numBatches > 1 && PerBatch) {
+        Result first = insPerm[0]();
+        if (!first.err.empty() || !first.image) return {nullptr, first.err.empty() ? "No input files to prepare batches" : first.err};
+        const int width = first.image->Naxisn[0];
+        const int height = (int)(first.image->Data.size() / (size_t)width);
+        const std::vector<int> devs = devices_for(c);
+        resident = nl_group_create((int)batchSize, width, height, (int)devs.size(), devs.data());
+        if (!resident) return {nullptr, nl_last_error()};
+        PerBatch->Resident = resident;
+    }
 
     ImagePtr stack;
     int64_t stackFrames = 0;
@@ -427,13 +486,22 @@ Result OpStackBatches::Apply(const std::vector<Promise> &ins, Context *c)
         Result batch = batchPromises[0]();                                                      // :92
         if (!batch.err.empty()) return {nullptr, batch.err};
         if (numBatches > 1) {                                                                   // :98-103
-            stack = StackIncremental(stack, batch.image, (float)batchFrames);
+            // StackIncremental on the devices; the host keeps the metadata (first batch seeds
+            // the stack, later ones add their exposure: stack.go:926-931)
+            if (nl_group_accumulate(resident, (float)batchFrames, stack ? 0 : 1) != NL_OK)
+                return {nullptr, nl_last_error()};
+            if (!stack) stack = batch.image;
+            else stack->Exposure += batch.image->Exposure;
             stackFrames += batchFrames;
         } else {
             stack = batch.image;
         }
     }
-    if (numBatches > 1) StackIncrementalFinalize(stack, (float)stackFrames);                    // :113-116
+    if (numBatches > 1) {                                                                       // :113-116
+        stack->Data.assign((size_t)stack->Pixels, 0.0f);
+        if (nl_group_accumulate_finalize(resident, (float)stackFrames, stack->Data.data()) != NL_OK)
+            return {nullptr, nl_last_error()};
+    }
     return {stack, ""};
 }
 
@@ -494,6 +562,14 @@ extern "C" int nl_host_op_stack_apply_json(const char *json, int n_frames, int w
     return 0;
 }
 
+// devices every operator of this process stacks on from now on (n <= 0: back to Context.Device)
+extern "C" int nl_host_set_devices(const int *devices, int n)
+{
+    if (n > 0 && devices) nightlight::host_devices().assign(devices, devices + n);
+    else nightlight::host_devices().clear();
+    return 0;
+}
+
 extern "C" const char *nl_host_op_stack_roundtrip_json(const char *json)
 {
     using namespace nightlight;
@@ -511,8 +587,8 @@ extern "C" const char *nl_host_op_stack_roundtrip_json(const char *json)
 extern "C" int nl_host_op_stack_batches_apply_json(const char *per_batch_json, int n_frames, int width, int height,
                                                    const float *const *frames, const float *exposure,
                                                    int device, int max_threads, int memory_mb, int stack_memory_mb,
-                                                   float *out, float *exposure_out, char *log_buf, int log_cap,
-                                                   char *err_buf, int err_cap)
+                                                   float *out, float *exposure_out, int *perm_out,
+                                                   char *log_buf, int log_cap, char *err_buf, int err_cap)
 {
     using namespace nightlight;
     auto put = [](char *dst, int cap, const std::string &s) {
@@ -546,6 +622,7 @@ extern "C" int nl_host_op_stack_batches_apply_json(const char *per_batch_json, i
     if (!err.empty()) { put(err_buf, err_cap, err); put(log_buf, log_cap, log.str()); return 1; }
     Result r = outs[0]();
     put(log_buf, log_cap, log.str());
+    if (perm_out) for (size_t i = 0; i < op->LastPerm.size() && i < (size_t)n_frames; i++) perm_out[i] = op->LastPerm[i];
     if (!r.err.empty() || !r.image) { put(err_buf, err_cap, r.err.empty() ? "no result" : r.err); return 1; }
     if (out) memcpy(out, r.image->Data.data(), r.image->Data.size() * sizeof(float));
     if (exposure_out) *exposure_out = r.image->Exposure;

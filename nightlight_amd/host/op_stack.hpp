@@ -5,6 +5,8 @@
 #pragma once
 #include "operator.hpp"
 
+struct nl_group;   // include/nlstack.h (C ABI): one stack over several devices
+
 namespace nightlight {
 
 enum StackMode { StMedian = 0, StMean, StSigma, StWinsorSigma, StMADSigma, StLinearFit, StAuto };   // stack.go:33-42
@@ -16,6 +18,10 @@ struct OpStack : Operator, OpBase {
     float SigmaLow = 2.75f;       // json:"sigmaLow"
     float SigmaHigh = 2.75f;      // json:"sigmaHigh"
     float RefFrameLoc = 0;        // json:"-"  (never assigned in the reference)
+    // not in the reference: a group of device handles the caller keeps across several Apply calls
+    // (OpStackBatches).  When set, Apply stacks on it and leaves the result tile on the devices
+    // (the returned image carries metadata only) for nl_group_accumulate.
+    ::nl_group *Resident = nullptr;
 
     std::string GetType() const override { return Type; }
     // stack.go:102-111: N inputs -> exactly one output promise
@@ -39,14 +45,16 @@ void RegisterOpStack();
 // weighted stack of stacks (StackIncremental / StackIncrementalFinalize, stack.go:924-944).
 struct OpStackBatches : Operator, OpBase {
     std::shared_ptr<OpStack> PerBatch;    // json:"perBatch"
+    std::vector<int> LastPerm;            // not in the reference: input index of every position after partition()
 
     std::string GetType() const override { return Type; }
     std::vector<Promise> MakePromises(const std::vector<Promise> &ins, Context *c,
                                       std::string *err) override;      // stackbatches.go:46-54
     Result Apply(const std::vector<Promise> &ins, Context *c);         // :56-119
-    // :121-217.  The reference shuffles the inputs with math/rand's global generator; this
-    // mirror uses a fixed-seed Fisher-Yates shuffle instead (the batch composition is a free
-    // choice of the algorithm, not part of its result contract).
+    // :121-217.  rand.Perm of the indices, then sort.Ints inside every batch (:199-209), so frames
+    // keep their original relative order within a batch.  The reference draws the permutation from
+    // math/rand's global generator; this mirror uses a fixed-seed Fisher-Yates (batch MEMBERSHIP is
+    // a free choice of the algorithm; the order inside a batch is not, and is kept).
     bool partition(const std::vector<Promise> &ins, Context *c, std::vector<Promise> *insPerm,
                    int64_t *numBatches, int64_t *batchSize, int64_t *maxThreads, std::string *err);
 };

@@ -64,7 +64,8 @@ struct Context {
     int MemoryMB = 0;                   // operator.go:40
     int StackMemoryMB = 0;              // operator.go:41 (MemoryMB*7/10)
     int StatsTotal = 0, StatsProcessed = 0;
-    int Device = 0;                     // not in the reference: which GPU the HIP operator uses
+    int Device = 0;                     // not in the reference: which GPU the HIP operator uses ...
+    std::vector<int> Devices;           // ... or several: one row tile of every stack per entry (nl_group_*)
 };
 
 std::vector<ImagePtr> RemoveNils(std::vector<ImagePtr> lights);

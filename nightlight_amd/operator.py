@@ -41,10 +41,20 @@ def op_stack_apply_json(text, frames, width, height, exposure=None, hfr=None, de
     return out, float(exp_out.value), log.value.decode()
 
 
+def set_devices(devices):
+    """Devices every host-side operator of this process stacks on (one row tile of each stack
+    per entry; a device may repeat).  None / empty: back to the `device` argument."""
+    lib = capi.load()
+    d = list(devices or [])
+    arr = (C.c_int * max(len(d), 1))(*d)
+    lib.nl_host_set_devices(arr, len(d))
+
+
 def op_stack_batches_apply_json(per_batch_json, frames, width, height, exposure=None, device=0,
-                                max_threads=4, memory_mb=0, stack_memory_mb=0):
+                                max_threads=4, memory_mb=0, stack_memory_mb=0, return_perm=False):
     """OpStackBatches (stackbatches.go:46-217) over host frames.
-    Returns (result, exposure_sum, log); raises OperatorError with the reference's message."""
+    Returns (result, exposure_sum, log[, perm]); raises OperatorError with the reference's message.
+    perm[i] = input index of position i after partitioning; batches are consecutive runs."""
     lib = capi.load()
     f32p = C.POINTER(C.c_float)
     keep = [np.ascontiguousarray(f, np.float32).reshape(-1) for f in frames]
@@ -53,11 +63,14 @@ def op_stack_batches_apply_json(per_batch_json, frames, width, height, exposure=
     exp_out = C.c_float(0)
     log = C.create_string_buffer(16384)
     err = C.create_string_buffer(1024)
+    perm = (C.c_int * max(len(keep), 1))()
     e = None if exposure is None else np.ascontiguousarray(exposure, np.float32)
     rc = lib.nl_host_op_stack_batches_apply_json(
         per_batch_json.encode(), len(keep), int(width), int(height), ptrs,
         None if e is None else capi.fptr(e), int(device), int(max_threads), int(memory_mb),
-        int(stack_memory_mb), capi.fptr(out), C.byref(exp_out), log, len(log), err, len(err))
+        int(stack_memory_mb), capi.fptr(out), C.byref(exp_out), perm, log, len(log), err, len(err))
     if rc != 0:
         raise OperatorError(err.value.decode() + ("\n" + log.value.decode() if log.value else ""))
+    if return_perm:
+        return out, float(exp_out.value), log.value.decode(), list(perm)[:len(keep)]
     return out, float(exp_out.value), log.value.decode()

@@ -93,6 +93,11 @@ class StackHandle:
     def attach_device_frames(self, ptr):
         capi.check(self._lib.nl_stack_attach_device_frames(self._h, C.c_void_p(ptr)))
 
+    def set_active_frames(self, n):
+        """Use frame slots [0, n) for the next uploads / passes (n <= the count given at creation)."""
+        capi.check(self._lib.nl_stack_set_active_frames(self._h, int(n)))
+        self.n_frames = int(n)
+
     def set_weights(self, weights):
         if weights is None:
             capi.check(self._lib.nl_stack_set_weights(self._h, None))
@@ -154,6 +159,27 @@ class StackHandle:
     @property
     def last_kernel_name(self):
         return self._lib.nl_stack_last_kernel_name(self._h).decode()
+
+    def pass_times(self, back=0):
+        """(pass ms, dominant-kernel ms) of the pass enqueued `back` passes ago, from the
+        handle's ring of HIP events -- no host sync was needed while the passes were queued."""
+        p, d = C.c_float(), C.c_float()
+        capi.check(self._lib.nl_stack_pass_times(self._h, int(back), C.byref(p), C.byref(d)))
+        return float(p.value), float(d.value)
+
+    @property
+    def stream_ptr(self):
+        """hipStream_t of the handle as an integer (torch.cuda.ExternalStream takes it)."""
+        return int(self._lib.nl_stack_stream(self._h) or 0)
+
+    def copy_counters_async(self, device_ptr):
+        """Enqueue a copy of the last pass's counters to a device buffer (2 x int64) on the handle's stream."""
+        capi.check(self._lib.nl_stack_copy_counters_async(self._h, C.c_void_p(int(device_ptr))))
+
+    @property
+    def counters_device_ptr(self):
+        """Device address of the last pass's {clip_low, clip_high} (2 x int64)."""
+        return int(self._lib.nl_stack_counters_device_ptr(self._h) or 0)
 
     def find_sigmas(self, mode, clip_perc_low, clip_perc_high, ref_loc=0.0, reduce=None,
                     fetch=True):
@@ -234,6 +260,80 @@ class StackHandle:
         raw = np.empty(self.tile_pixels * 4, np.uint8)
         capi.check(self._lib.nl_stack_download_result_fits(self._h, raw.ctypes.data_as(C.c_void_p)))
         return raw
+
+
+class StackGroup:
+    """nl_group_*: one stack over several GPUs from one process -- tile t owns the rows
+    group_tile_rows(height, n_tiles, t) of all frames on devices[t]; counters summed on the
+    host (stack.go:142-152, 193-198).  devices=None: one tile per visible device."""
+
+    def __init__(self, n_frames, width, height, n_tiles=0, devices=None):
+        self._lib = capi.load()
+        self.n_frames, self.width, self.height = int(n_frames), int(width), int(height)
+        dev = None
+        if devices is not None:
+            n_tiles = len(devices)
+            dev = (C.c_int * n_tiles)(*[int(d) for d in devices])
+        self._g = self._lib.nl_group_create(self.n_frames, self.width, self.height, int(n_tiles), dev)
+        if not self._g:
+            raise capi.NlError(capi.ERR_HIP, capi.last_error())
+        self.size = self._lib.nl_group_size(self._g)
+
+    def close(self):
+        if self._g:
+            self._lib.nl_group_destroy(self._g)
+            self._g = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def tile_rows(self, t):
+        r0, nr = C.c_int(), C.c_int()
+        self._lib.nl_group_tile_rows(self.height, self.size, int(t), C.byref(r0), C.byref(nr))
+        return r0.value, nr.value
+
+    def upload_frames(self, frames):
+        for i, f in enumerate(frames):
+            f = np.ascontiguousarray(f, dtype=np.float32).reshape(-1)
+            assert f.size == self.width * self.height
+            capi.check(self._lib.nl_group_upload_frame(self._g, i, capi.fptr(f)))
+
+    def fill_synthetic(self, seed=0x4E4C5354):
+        capi.check(self._lib.nl_group_fill_synthetic(self._g, C.c_uint64(seed)))
+
+    def set_weights(self, weights):
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float32)
+        capi.check(self._lib.nl_group_set_weights(self._g, capi.fptr(w) if w is not None else None))
+
+    def set_exact(self, on=True):
+        capi.check(self._lib.nl_group_set_exact(self._g, int(on)))
+
+    def run(self, mode, sigma_low=2.75, sigma_high=2.75, ref_loc=0.0):
+        out = np.zeros(self.width * self.height, np.float32)
+        cl, ch = C.c_int64(0), C.c_int64(0)
+        capi.check(self._lib.nl_group_run(self._g, int(mode), C.c_float(sigma_low), C.c_float(sigma_high),
+                                          C.c_float(ref_loc), capi.fptr(out), C.byref(cl), C.byref(ch)))
+        return out, cl.value, ch.value
+
+    def find_sigmas(self, mode, clip_perc_low, clip_perc_high, ref_loc=0.0):
+        out = np.zeros(self.width * self.height, np.float32)
+        cl, ch = C.c_int64(0), C.c_int64(0)
+        sl, sh, passes = C.c_float(), C.c_float(), C.c_int()
+        capi.check(self._lib.nl_group_find_sigmas(
+            self._g, int(mode), C.c_float(ref_loc), C.c_float(clip_perc_low), C.c_float(clip_perc_high),
+            capi.fptr(out), C.byref(cl), C.byref(ch), C.byref(sl), C.byref(sh), C.byref(passes)))
+        return out, cl.value, ch.value, float(sl.value), float(sh.value), passes.value
+
+    def accumulate(self, weight, first):
+        capi.check(self._lib.nl_group_accumulate(self._g, C.c_float(weight), int(bool(first))))
+
+    def accumulate_finalize(self, weight_sum):
+        out = np.zeros(self.width * self.height, np.float32)
+        capi.check(self._lib.nl_group_accumulate_finalize(self._g, C.c_float(weight_sum), capi.fptr(out)))
+        return out
 
 
 def fits_decode(raw, bitpix, bscale=1.0, bzero=0.0, device=0):

@@ -1,0 +1,158 @@
+"""Multi-GPU forms of the path on ONE device (the GPU box has a single MI355X):
+
+* two torch.distributed ranks (gloo, both on device 0) each run the HIP path on
+  their own row tile and exchange only the two clip counters; the tiles
+  reassemble the oracle's single-image result (stack.go:142-152, 193-198);
+* nl_group_*: the single-process fan-out over n tiles (what the Go shim and the
+  C++ operator mirror call), tiles all on device 0 here;
+* bench.py --gpus 2 launches its own ranks and reports strong scaling.
+RCCL itself (backend nccl over xGMI) needs >= 2 GPUs and is exercised by the
+driver's scaling run; everything around the collective is the same code."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from util import bits_equal, make_frames
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, N = 160, 90, 20          # 90 rows over 2 / 3 / 4 tiles: uneven splits
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import nightlight_amd as nl
+    from nightlight_amd.dist import ShardedStack
+    from util import make_frames as mk
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = mk(N, W, H, seed=7100)
+
+    def make_tile(row0, rows):
+        st = nl.StackHandle(N, W, H, row0=row0, rows=rows, device=0)     # both ranks share device 0
+        st.upload_frames(frames)
+        return st
+
+    sh = ShardedStack(H, make_tile, world=world, rank=rank, device="cpu")
+    out = {}
+    for mode in (2, 3, 5):
+        res, cl, ch = sh.run(mode, 2.5, 2.5)
+        out["res%d" % mode] = res
+        out["clip%d" % mode] = np.array([cl, ch])
+    gs = sh.find_sigmas(2, 1.0, 1.0)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), row0=sh.row0, rows=sh.rows,
+             gs_res=gs[0], gs=np.array(gs[1:], np.float64), **out)
+    sh.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_shard_the_hip_path(tmp_path, oracle, nl):
+    import torch.multiprocessing as mp
+    world, port = 2, 29600 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    frames = make_frames(N, W, H, seed=7100)
+    ranks = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for mode in (2, 3, 5):
+        rc, want, wl, wh, _ = oracle.stack_apply(mode, frames, None, 2.5, 2.5)
+        full = np.zeros(W * H, np.float32)
+        for d in ranks:
+            r0, rows = int(d["row0"]), int(d["rows"])
+            full[r0 * W:(r0 + rows) * W] = d["res%d" % mode][r0 * W:(r0 + rows) * W]
+            assert tuple(d["clip%d" % mode]) == (wl, wh)          # every rank holds the GLOBAL totals
+        assert np.array_equal(np.isnan(full), np.isnan(want))
+        ok = ~np.isnan(want)
+        assert np.all(np.abs(full[ok].astype(np.float64) - want[ok]) <= 1e-5 * np.abs(want[ok]))
+    passes, gres, gcl, gch, gsl, gsh = oracle.find_sigmas_bisect(2, frames, 1.0, 1.0)
+    gfull = np.zeros(W * H, np.float32)
+    for d in ranks:
+        r0, rows = int(d["row0"]), int(d["rows"])
+        gfull[r0 * W:(r0 + rows) * W] = d["gs_res"][r0 * W:(r0 + rows) * W]
+        assert tuple(d["gs"][:2]) == (gcl, gch) and int(d["gs"][4]) == passes
+        assert (np.float32(d["gs"][2]), np.float32(d["gs"][3])) == (gsl, gsh)
+    ok = ~np.isnan(gres)
+    assert np.all(np.abs(gfull[ok].astype(np.float64) - gres[ok]) <= 1e-5 * np.abs(gres[ok]))
+
+
+@pytest.mark.parametrize("tiles", [1, 3, 4])
+def test_group_fans_one_stack_out_over_tiles(nl, oracle, tiles):
+    frames = make_frames(N, W, H, seed=7200 + tiles)
+    w = (0.3 + 0.7 * ((np.arange(N) * 13) % 17) / 16.0).astype(np.float32)
+    with nl.StackGroup(N, W, H, devices=[0] * tiles) as g:
+        assert g.size == tiles
+        spans = [g.tile_rows(t) for t in range(tiles)]
+        assert spans[0][0] == 0 and sum(r for _, r in spans) == H
+        assert all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        g.upload_frames(frames)
+        for mode, weights, exact in ((0, None, True), (1, w, True), (2, None, False), (2, w, True), (3, None, False),
+                                     (4, None, False), (5, None, True)):
+            g.set_weights(weights)
+            got, cl, ch = g.run(mode, 2.0, 2.5)
+            ow = None if mode in (0, 5) else weights
+            rc, want, wl, wh, _ = oracle.stack_apply(mode, frames, ow, 2.0, 2.5)
+            assert rc == 0
+            if mode >= 2:
+                assert (cl, ch) == (wl, wh), (mode, tiles)
+            if exact:
+                assert bits_equal(got, want), (mode, tiles)
+            else:
+                ok = ~np.isnan(want)
+                assert np.array_equal(np.isnan(got), np.isnan(want))
+                assert np.all(np.abs(got[ok].astype(np.float64) - want[ok]) <= 1e-5 * np.abs(want[ok]))
+        # goal-seek with host-summed counters takes the oracle's branches
+        g.set_weights(None)
+        res, cl, ch, sl, sh, passes = g.find_sigmas(2, 1.0, 1.5)
+        op, ores, ocl, och, osl, osh = oracle.find_sigmas_bisect(2, frames, 1.0, 1.5)
+        assert (cl, ch, np.float32(sl), np.float32(sh), passes) == (ocl, och, osl, osh, op)
+        # stack of stacks across the tiles
+        g.run(1)
+        g.accumulate(3.0, True)
+        g.accumulate(2.0, False)
+        acc = g.accumulate_finalize(5.0)
+        rc, mean, _, _, _ = oracle.stack_apply(1, frames, None)
+        a = oracle.stack_incremental(np.zeros_like(mean), mean, 3.0, True)
+        a = oracle.stack_incremental(a, mean, 2.0, False)
+        assert bits_equal(acc, oracle.stack_incremental_finalize(a, 5.0))
+
+
+def test_group_errors_follow_the_handle(nl):
+    from nightlight_amd import capi
+    with nl.StackGroup(4, 32, 16, devices=[0, 0]) as g:
+        g.set_weights(np.ones(4, np.float32))
+        with pytest.raises(capi.NlError) as e:
+            g.run(4)                      # weighted MAD: the reference panics, we return its message
+        assert e.value.code == capi.ERR_WEIGHTED_MAD
+        with pytest.raises(capi.NlError) as e:
+            g.run(9)
+        assert e.value.message == "invalid stacking mode"
+    with pytest.raises(capi.NlError):
+        nl.StackGroup(4, 32, 16, devices=[0, 99])
+
+
+def test_bench_self_launches_ranks_and_reports_strong_scaling():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device",
+           "--frames", "16", "--width", "256", "--height", "96", "--steps", "3", "--warmup", "1", "--no-cpu"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["scaling"] == "strong"
+    assert doc["config"]["image_rows"] == 96 and doc["config"]["rows_per_gpu"] == 48
+    # same stack on one rank: same global counters, twice the rows per GPU
+    p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "16", "--width", "256",
+                         "--height", "96", "--steps", "3", "--warmup", "1", "--no-cpu"],
+                        env=env, capture_output=True, text=True, timeout=280)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    one = json.loads([ln for ln in p1.stdout.splitlines() if ln.startswith("{")][0])
+    assert one["n_gpus"] == 1 and one["config"]["rows_per_gpu"] == 96
+    assert (one["config"]["clip_low"], one["config"]["clip_high"]) == (doc["config"]["clip_low"], doc["config"]["clip_high"])
+    assert one["roofline"]["timed_passes_averaged"] == 3 and one["roofline"]["kernel_ms"] > 0

@@ -124,19 +124,86 @@ def test_stack_batches_partition_log_and_stack_of_stacks(nl, oracle):
     assert "Randomizing input files into batches...\n" in log
     for b, k in ((1, 8), (2, 8), (3, 7)):
         assert "\nStarting batch %d of 3 with %d frames...\n" % (b, k) in log                       # :78
-    # every frame lands in exactly one batch; the result is the frame-count weighted mean of the
-    # batch stacks (StackIncremental / Finalize): check against the oracle for SOME partition of
-    # that shape by recovering the batches from the log's clip lines is not possible, so check
-    # the invariants: finite where any frame has data, and equal to the oracle when all batches
-    # are stacked with the plain mean (order-insensitive up to rounding)
     assert exp_sum == float(np.float32(sum(np.float32(x) for x in exposure)))
-    out_mean, _, _ = op.op_stack_batches_apply_json('{"type":"stack","mode":1}', list(frames), width, height,
-                                                    exposure=exposure, max_threads=2, memory_mb=20,
-                                                    stack_memory_mb=12)
-    rc, want, _, _, _ = oracle.stack_apply(1, frames, None, 0, 0)
-    has_all = ~np.isnan(frames).any(axis=0)         # pixels present in every frame: batch means recombine exactly
-    assert np.allclose(out_mean[has_all], want[has_all], rtol=2e-6, atol=0)
-    assert np.isfinite(out[has_all]).all()
+    _check_batches_against_oracle(op, oracle, frames, width, height, exposure, (3, 8), devices=None)
+
+
+def _oracle_stack_of_stacks(oracle, frames, perm, bs, mode, sl, sh):
+    """The reference's batch loop (stackbatches.go:69-116) on the oracle for a given partition:
+    per-batch stack with the frames in perm order, StackIncremental weighted by the batch frame
+    count, StackIncrementalFinalize.  Returns (result, [(clipLow, clipHigh) per batch])."""
+    acc, clips, total = None, [], 0
+    for start in range(0, len(perm), bs):
+        idx = perm[start:start + bs]
+        rc, res, cl, ch, _ = oracle.stack_apply(mode, np.ascontiguousarray(frames[idx]), None, sl, sh, 0.0, num_cpu=4)
+        assert rc == 0
+        clips.append((cl, ch))
+        acc = oracle.stack_incremental(np.zeros_like(res) if acc is None else acc, res, float(len(idx)),
+                                       first=acc is None)
+        total += len(idx)
+    return oracle.stack_incremental_finalize(acc, float(total)), clips
+
+
+def _check_batches_against_oracle(op, oracle, frames, width, height, exposure, shape, devices):
+    import re
+    nb, bs = shape
+    n = frames.shape[0]
+    op.set_devices(devices)
+    try:
+        # (a) mean per batch: every kernel on the way is bit-exact, so the whole stack of stacks must
+        # equal the oracle's for the SAME partition bit for bit -- this sees the frame order inside a
+        # batch (fp32 sums in frame order) and the device-side StackIncremental / Finalize
+        out, _, log, perm = op.op_stack_batches_apply_json('{"type":"stack","mode":1}', list(frames), width, height,
+                                                           exposure=exposure, max_threads=2, memory_mb=20,
+                                                           stack_memory_mb=12, return_perm=True)
+        assert sorted(perm) == list(range(n))                            # every frame in exactly one batch
+        assert perm != list(range(n))                                    # batches are random ...
+        for start in range(0, n, bs):                                    # ... and sorted inside (stackbatches.go:199-209)
+            assert perm[start:start + bs] == sorted(perm[start:start + bs])
+        want, _ = _oracle_stack_of_stacks(oracle, frames, perm, bs, 1, 0.0, 0.0)
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), \
+            "%d pixels differ" % np.count_nonzero(out.view(np.uint32) != want.view(np.uint32))
+        # (b) sigma clipping per batch (register-resident kernels: counters exact, values 1e-5): the
+        # per-batch "Clipped low" log lines carry the oracle's counters for that partition
+        out, _, log, perm2 = op.op_stack_batches_apply_json(
+            '{"type":"stack","mode":2,"sigmaLow":2.5,"sigmaHigh":2.5}', list(frames), width, height,
+            exposure=exposure, max_threads=2, memory_mb=20, stack_memory_mb=12, return_perm=True)
+        assert perm2 == perm                                             # fixed-seed permutation
+        want, clips = _oracle_stack_of_stacks(oracle, frames, perm, bs, 2, 2.5, 2.5)
+        got_clips = [(int(a), int(b)) for a, b in re.findall(r"Clipped low (\d+) \([0-9.]+%\) high (\d+) ", log)]
+        assert got_clips == clips
+        ok = ~np.isnan(want) & (want != 0)
+        assert np.array_equal(np.isnan(out), np.isnan(want))
+        assert np.max(np.abs(out[ok].astype(np.float64) - want[ok]) / np.abs(want[ok])) <= 1e-5
+    finally:
+        op.set_devices(None)
+
+
+@pytest.mark.gpu
+def test_stack_batches_over_several_device_tiles(nl, oracle):
+    # the same batch loop with every stack fanned out over 3 row tiles (nl_group_*; all on device 0
+    # here): tiles never change a pixel's arithmetic, so the same oracle comparison must hold
+    from nightlight_amd import operator as op
+    width, height, n = 512, 512, 23
+    frames = make_frames(n, width, height, seed=41)
+    _check_batches_against_oracle(op, oracle, frames, width, height, np.full(n, 10.0, np.float32), (3, 8),
+                                  devices=[0, 0, 0])
+
+
+@pytest.mark.gpu
+def test_op_stack_apply_over_several_device_tiles(nl, oracle):
+    from nightlight_amd import operator as op
+    width, height, n = 96, 50, 12
+    frames = make_frames(n, width, height, seed=43)
+    op.set_devices([0, 0, 0, 0])
+    try:
+        out, _, log = op.op_stack_apply_json('{"type":"stack","mode":3}', list(frames), width, height)
+    finally:
+        op.set_devices(None)
+    rc, want, wl, wh, _ = oracle.stack_apply(3, frames, None, 2.75, 2.75)
+    assert "Clipped low %d (" % wl in log and " high %d (" % wh in log           # host-summed over the tiles
+    ok = ~np.isnan(want) & (want != 0)
+    assert np.max(np.abs(out[ok].astype(np.float64) - want[ok]) / np.abs(want[ok])) <= 1e-5
 
 
 @pytest.mark.gpu

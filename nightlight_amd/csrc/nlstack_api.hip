@@ -697,6 +697,21 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
         h->last_has_counters = true;
         h->last_used_fast = true;
+    } else if ((h->exact_flavour == 3 || (!h->force_exact && weighted && a.n_frames <= nl::kTileMaxFramesDefault)) &&
+               nl::tile_supported(mode, weighted, a.n_frames)) {
+        // bit-exact replay over the whole tile, 64 consecutive pixels per wave with their columns in
+        // LDS, one pixel per lane: the default for weighted sigma / winsorized clipping (their result
+        // depends on the reference's permutation, so there is no register-resident shortcut) up to
+        // 64 frames -- the LDS column limits it to one wave per SIMD at 128 frames, where the
+        // wave-per-pixel replay below is faster (tools/replay_probe.py: 0.5 vs 1.5 ms per Mpixel at
+        // 32 frames, 7.7 vs 3.8 at 128); nl_stack_set_exact(h, 3) forces it (verification)
+        h->last_used_fast = false;
+        const int64_t tiles = (a.npix + 63) / 64;
+        const int64_t g = tiles < (1 << 20) ? tiles : (1 << 20);
+        NL_HIP(nl::launch_stack_sigma_tile(mode, a, (int)g, h->stream, &h->last_kernel));
+        NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
+        NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
+        h->last_has_counters = true;
     } else if ((h->exact_flavour == 2 || (!h->force_exact && (weighted || a.n_frames > 512))) &&
                nl::coop_supported(mode, weighted, a.n_frames)) {
         // the wave-per-pixel exact replay over the whole tile: the default for weighted sigma /

@@ -114,6 +114,12 @@ int coop_supported(int mode, bool weighted, int n_frames);
 hipError_t launch_stack_median_coop(const StackArgs &args, int grid, hipStream_t stream, const char **name);
 hipError_t launch_stack_sigma_coop(int mode, const StackArgs &args, int grid, hipStream_t stream, const char **name);
 
+// ---- stack_exact_tile.hip (bit-exact sigma / winsorized clipping over whole tiles: one wave = 64
+// consecutive pixels, columns in LDS, one pixel per lane; the weighted modes' default path) ----
+constexpr int kTileMaxFramesDefault = 64;      // frame counts up to which it beats the wave-per-pixel replay
+int tile_supported(int mode, bool weighted, int n_frames);
+hipError_t launch_stack_sigma_tile(int mode, const StackArgs &args, int grid, hipStream_t stream, const char **name);
+
 // ---- stack_linfit.hip (register-resident linear fit, bit-exact) ----
 // Cascade: a stage runs at most max_iters fit iterations; pixels that are not done are
 // appended to out_list together with their liveness mask (4 words) and continued by the

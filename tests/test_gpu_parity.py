@@ -201,6 +201,62 @@ def test_fast_sigma_clean_frames_no_nan(nl, oracle):
     assert gc == wc and close_values(got, want)
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 33, 64, 65, 127, 128, 130, 256, 300, 420])
+def test_tile_exact_replay_is_bit_exact(nl, oracle, n):
+    # stack_exact_tile.hip: one wave = 64 consecutive pixels, columns in LDS, one pixel per lane,
+    # quickselect as a lock-step state machine; forced here for every pixel (set_exact(3)).
+    # 200 px wide: full tiles, a ragged last tile, NaN borders, all-NaN pixels, ties.
+    width, height = 200, 3
+    frames = make_frames(n, width, height, seed=1900 + n, ties=(n % 2 == 1))
+    weights = np.random.default_rng(n).uniform(0.2, 1.0, n).astype(np.float32)
+    for mode in (2, 3):                   # sigma, winsorized sigma
+        for kappa in (2.75, 1.0):
+            for w in (None, weights):     # weighted: the weights follow the clip swaps only (stack.go:487)
+                with nl.StackHandle(n, width, height) as st:
+                    st.upload_frames(frames)
+                    st.set_weights(w)
+                    st.set_exact(3)
+                    got, cl, ch = st.run(mode, kappa, kappa, 0.0)
+                    # (above 256 frames the weight indices are 16-bit: 420 frames still fit the 160 KiB LDS)
+                    assert st.last_kernel_name.startswith("stack_sigma_tile_kernel"), st.last_kernel_name
+                rc, want, wl, wh, _ = oracle.stack_apply(mode, frames, w, kappa, kappa, 0.0, num_cpu=4)
+                assert same_values(got, want), "tile %s n=%d w=%s: %s" % (
+                    MODES[mode], n, w is not None, describe_mismatch(got, want))
+                assert (cl, ch) == (wl, wh)
+
+
+def test_tile_replay_heavy_clipping_and_degenerate_bounds(nl, oracle):
+    # many clips per pixel (swap-with-last chains, clipped samples arriving from the tail),
+    # negative / zero sigmas (inverted bounds: everything clipped), constant pixels (stddev 0)
+    width, height, n = 128, 2, 40
+    frames = make_frames(n, width, height, seed=77, hot=0.2, cold=0.15, nan_frac=0.1)
+    frames[:, 5] = 42.0
+    frames[:, 6] = np.where(np.arange(n) % 2 == 0, 1.0, 3.0)
+    w = np.random.default_rng(3).uniform(0.2, 1.0, n).astype(np.float32)
+    for mode in (2, 3):
+        for sl, sh in ((0.5, 0.5), (0.0, 3.0), (-1.0, -1.0), (3.0, 0.25)):
+            for weights in (None, w):
+                with nl.StackHandle(n, width, height) as st:
+                    st.upload_frames(frames)
+                    st.set_weights(weights)
+                    st.set_exact(3)
+                    got, cl, ch = st.run(mode, sl, sh, 7.0)
+                rc, want, wl, wh, _ = oracle.stack_apply(mode, frames, weights, sl, sh, 7.0, num_cpu=4)
+                assert same_values(got, want), "%s (%g,%g): %s" % (MODES[mode], sl, sh, describe_mismatch(got, want))
+                assert (cl, ch) == (wl, wh)
+
+
+def test_weighted_clip_modes_default_dispatch(nl):
+    # up to 64 frames the tile kernel, above it the wave-per-pixel replay (faster there)
+    for n, prefix in ((16, "stack_sigma_tile_kernel<"), (64, "stack_sigma_tile_kernel<"), (65, "stack_sigma_coop_kernel<")):
+        with nl.StackHandle(n, 64, 4) as st:
+            st.fill_synthetic(1)
+            st.set_weights(np.linspace(0.2, 1.0, n).astype(np.float32))
+            for mode in (2, 3):
+                st.run(mode, 2.0, 2.0)
+                assert st.last_kernel_name.startswith(prefix), st.last_kernel_name
+
+
 @pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("n", [2, 7, 16, 33, 128])
 def test_weighted_modes_match_oracle(nl, oracle, mode, n):

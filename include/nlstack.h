@@ -171,9 +171,13 @@ int64_t nl_stack_last_fallback_pixels(nl_stack_t *h);
 /* Name of the dominant kernel launched by the last pass (for profiles). */
 const char *nl_stack_last_kernel_name(nl_stack_t *h);
 
-/* ---- goal-seek (spec: internal/ops/stack/stackfindsigma.go:48-98) ----
- * Bisection on sigma_low / sigma_high in [1,11] until the clipped
- * percentages match the targets to 0.01 % or 21 passes were made.  After each
+/* ---- goal-seek (spec: internal/ops/stack/stackfindsigma.go:27-170, FindSigmasAndStack) ----
+ * Sigma / winsorized sigma (:48-98): bisection on sigma_low / sigma_high in [1,11] until
+ * the clipped percentages match the targets to 0.01 % or 21 passes were made.
+ * Linear fit (:101-170): Newton's method from (6, 6) with probe passes at +0.005, the
+ * reference's quirks included (both high deltas are taken against the LOW target; the
+ * step counter advances by three per iteration).  Other modes "do not support sigmas":
+ * one pass with 0, 0; the returned sigmas are 0 (:42-46).  After each
  * pass the tile's {clip_low, clip_high} are handed to `reduce` (may be NULL
  * for a single tile) which must replace them with the totals over all tiles
  * -- e.g. an RCCL all-reduce -- so every rank takes the same branch.
@@ -275,6 +279,15 @@ int nl_project_bilinear(const float *src_host, int src_w, int src_h, float *dst_
 /* ---- 3x3 spatial median filter (internal/median/median3x3.go:26-110) ----
  * host in/out, width*height floats each; border rows/columns copied. */
 int nl_median_filter_3x3(const float *in_host, float *out_host, int width, int height, int device);
+/* ---- MedianFilter = GatherAndMedian over every pixel (internal/median/gather.go:26-38,
+ * internal/ops/pre/badpixels.go:54-77, MedianFloat32 median3x3.go:115-119) ----
+ * out[i] = median of in[i + mask[j]] over the offsets that fall inside [0, n); mask as
+ * star.CreateMask builds it (findstars.go:187-200), at most 32 offsets.  Even counts
+ * average the two middle values (qsort.go:68-82).  Where the whole neighbourhood exists
+ * this equals the reference; at the data's edges the reference's value depends on the
+ * leftovers of earlier calls in its scratch buffer, here it is the median of what exists. */
+int nl_median_filter_mask(const float *in_host, float *out_host, int64_t n, const int32_t *mask,
+                          int mask_len, int device);
 
 /* ---- host-side operator mirror (nightlight_amd/host/, C++) ----
  * The reference's stack operator decoded from its JSON form and run through

@@ -44,7 +44,7 @@ EXPORTS = [
     "nl_stack_set_exact", "nl_stack_last_fallback_pixels",
     "nl_stack_find_sigmas", "nl_stack_accumulate", "nl_stack_accumulate_finalize",
     "nl_stack_frame_stats", "nl_stack_frame_noise", "nl_stack_weights_from_noise",
-    "nl_median_filter_3x3",
+    "nl_median_filter_3x3", "nl_median_filter_mask",
     "nl_stack_upload_frame_fits", "nl_stack_upload_frame_projected", "nl_stack_frame_affine",
     "nl_stack_download_result_fits", "nl_fits_decode", "nl_project_bilinear",
     "nl_host_op_stack_apply_json", "nl_host_op_stack_roundtrip_json", "nl_host_set_devices",
@@ -148,6 +148,7 @@ def load():
     L.nl_stack_frame_noise.argtypes = [vp, C.c_int, _f32p]
     L.nl_stack_weights_from_noise.argtypes = [vp, _f32p]
     L.nl_median_filter_3x3.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int]
+    L.nl_median_filter_mask.argtypes = [_f32p, _f32p, C.c_int64, C.POINTER(C.c_int32), C.c_int, C.c_int]
     L.nl_stack_upload_frame_async.argtypes = [vp, C.c_int, _f32p]
     L.nl_stack_upload_wait.argtypes = [vp]
     L.nl_stack_upload_frame_fits.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, C.c_float,

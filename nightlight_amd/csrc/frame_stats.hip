@@ -182,6 +182,58 @@ __global__ __launch_bounds__(256) void median3x3_kernel(const float *in, float *
     }
 }
 
+// GatherAndMedian over every pixel = MedianFilter (internal/median/gather.go:26-38,
+// internal/ops/pre/badpixels.go:54-77; masks from star/findstars.go:187-200, <= 21 offsets for
+// the radii the reference uses, kMaskMax here).  One pixel per lane, the neighbourhood in
+// registers.  MedianFloat32 (median3x3.go:115-119) is order independent, so instead of replaying
+// quickselect the kernel ranks by counting: x_j is the k-th smallest iff #{x < x_j} <= k <
+// #{x <= x_j}; odd count -> the middle value, even count -> 0.5 * (lower + upper) exactly as
+// qsort.go:68-82 (the 9-value network of median3x3.go:85-110 returns the same middle value).
+// Where part of the neighbourhood falls outside the data the reference's result depends on what
+// earlier calls left in its scratch buffer (gather.go:37 takes the median of the WHOLE buffer);
+// here it is the median of the values that exist -- the only history-free reading.
+constexpr int kMaskMax = 32;
+struct MaskArg { int off[kMaskMax]; };
+
+__global__ __launch_bounds__(256) void median_mask_kernel(const float *in, float *out, int64_t n, MaskArg m, int len)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x[kMaskMax];
+    int num = 0;
+#pragma unroll
+    for (int j = 0; j < kMaskMax; j++) {
+        const int64_t io = i + m.off[j];
+        const bool ok = j < len && io >= 0 && io < n;
+        x[j] = ok ? in[io] : __builtin_inff();          // missing: +Inf, never the k-th smallest for k < num
+        num += ok ? 1 : 0;
+    }
+    const int ku = num >> 1, kl = ku - 1;
+    float upper = 0.0f, lower = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kMaskMax; j++) {
+        int lt = 0, le = 0;
+#pragma unroll
+        for (int t = 0; t < kMaskMax; t++) {
+            lt += (x[t] < x[j]) ? 1 : 0;
+            le += (x[t] <= x[j]) ? 1 : 0;
+        }
+        if (lt <= ku && ku < le) upper = x[j];
+        if (lt <= kl && kl < le) lower = x[j];
+    }
+    float res = (num & 1) ? upper : 0.5f * (lower + upper);
+    if (num == 0) res = __builtin_nanf("");                 // median3x3.go:116
+    out[i] = res;
+}
+
+hipError_t launch_median_mask(const float *in, float *out, int64_t n, const int *mask, int len, hipStream_t stream)
+{
+    MaskArg m;
+    for (int j = 0; j < kMaskMax; j++) m.off[j] = j < len ? mask[j] : 0;
+    hipLaunchKernelGGL(median_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, out, n, m, len);
+    return hipGetLastError();
+}
+
 hipError_t launch_min_sum_max(const float *data, int64_t n, double *partial, int blocks,
                               hipStream_t stream)
 {

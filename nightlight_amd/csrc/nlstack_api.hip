@@ -854,12 +854,42 @@ int nl_stack_find_sigmas(nl_stack_t *h, int mode, float ref_loc,
 {
     NL_CHECK_HANDLE(h);
     if (mode == NL_ST_AUTO) mode = auto_select_mode(h->n_frames);
-    if (mode != NL_ST_SIGMA && mode != NL_ST_WINSOR_SIGMA)
-        return fail(NL_ERR_INVALID_MODE, "goal-seek bisection supports sigma and winsorized sigma only");
+    if (mode < NL_ST_MEDIAN || mode > NL_ST_LINEAR_FIT) return fail(NL_ERR_INVALID_MODE, "invalid stacking mode");
     // the counters cover the samples the percentages are taken of: with a reducer the whole
     // image (every tile contributes), without one only this handle's tile
     const int64_t total = reduce ? (int64_t)h->width * h->height * (int64_t)h->n_frames
                                  : h->npix * (int64_t)h->n_frames;
+    if (mode != NL_ST_SIGMA && mode != NL_ST_WINSOR_SIGMA) {
+        // stackfindsigma.go:40-46: Newton's method for the linear fit; the other modes "do not support
+        // sigmas" and are stacked once with 0, 0
+        nl::SigmaNewton nw(clip_perc_low, total);
+        int n_pass = 0;
+        for (;;) {
+            const bool newton = mode == NL_ST_LINEAR_FIT;
+            int64_t c[2] = {0, 0};
+            int rc = nl_stack_run(h, mode, newton ? nw.next_low() : 0.0f, newton ? nw.next_high() : 0.0f, ref_loc,
+                                  nullptr, &c[0], &c[1]);
+            if (rc != NL_OK) return rc;
+            n_pass++;
+            if (reduce) {
+                rc = reduce(c, user);
+                if (rc != 0) return fail(NL_ERR_INVALID_ARG, "counter reduction callback failed (%d)", rc);
+            }
+            const int st = newton ? nw.step(c[0], c[1]) : 1;
+            if (st == 0) continue;
+            if (st == 2) {                       // a probe pass overwrote the result: re-make the base pass
+                rc = nl_stack_run(h, mode, nw.sig_low, nw.sig_high, ref_loc, nullptr, nullptr, nullptr);
+                if (rc != NL_OK) return rc;
+            }
+            if (clip_low) *clip_low = newton ? nw.base_lo : c[0];
+            if (clip_high) *clip_high = newton ? nw.base_hi : c[1];
+            if (sigma_low) *sigma_low = newton ? nw.sig_low : 0.0f;
+            if (sigma_high) *sigma_high = newton ? nw.sig_high : 0.0f;
+            if (passes) *passes = n_pass;
+            if (out_host) return nl_stack_finish(h, out_host, nullptr, nullptr);
+            return NL_OK;
+        }
+    }
     nl::SigmaBisection bis(clip_perc_low, clip_perc_high, total);
     int n_pass = 0;
     for (;;) {
@@ -1138,6 +1168,31 @@ int nl_project_bilinear(const float *src_host, int src_w, int src_h, float *dst_
     if (rc == NL_OK) rc = nl_stack_download_tile(h, 0, dst_host);
     nl_stack_destroy(h);
     return rc;
+}
+
+// MedianFilter / GatherAndMedian, ops/pre/badpixels.go:54-77 and internal/median/gather.go:26-38
+int nl_median_filter_mask(const float *in_host, float *out_host, int64_t n, const int32_t *mask, int mask_len, int device)
+{
+    if (!in_host || !out_host || n < 1 || !mask || mask_len < 1 || mask_len > nl::kMedianMaskMax)
+        return fail(NL_ERR_INVALID_ARG, "median_filter_mask: bad argument (mask of 1..%d offsets)", nl::kMedianMaskMax);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(NL_ERR_NO_DEVICE, "no HIP device available; libnlstack has no CPU path");
+    NL_HIP(hipSetDevice(device));
+    const size_t bytes = (size_t)n * sizeof(float);
+    float *d_in = nullptr, *d_out = nullptr;
+    NL_HIP(hipMalloc(&d_in, bytes));
+    hipError_t e = hipMalloc(&d_out, bytes);
+    if (e != hipSuccess) { (void)hipFree(d_in); return fail(NL_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    do {
+        if ((e = hipMemcpy(d_in, in_host, bytes, hipMemcpyHostToDevice)) != hipSuccess) break;
+        if ((e = nl::launch_median_mask(d_in, d_out, n, mask, mask_len, nullptr)) != hipSuccess) break;
+        if ((e = hipMemcpy(out_host, d_out, bytes, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    } while (0);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(NL_ERR_HIP, "median_filter_mask: %s", hipGetErrorString(e));
+    return NL_OK;
 }
 
 int nl_median_filter_3x3(const float *in_host, float *out_host, int width, int height, int device)

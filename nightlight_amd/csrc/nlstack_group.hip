@@ -153,35 +153,58 @@ int nl_group_find_sigmas(nl_group_t *g, int mode, float ref_loc, float clip_perc
                          float *sigma_low, float *sigma_high, int *passes)
 {
     if (!g || g->tiles.empty()) return NL_ERR_INVALID_ARG;
-    nl::SigmaBisection bis(clip_perc_low, clip_perc_high,
-                           (int64_t)g->width * g->height * (int64_t)g->n_frames);
-    int n_pass = 0;
-    for (;;) {
-        int64_t lo = 0, hi = 0;
-        int rc = nl_group_run(g, mode, bis.low_mid, bis.high_mid, ref_loc, nullptr, &lo, &hi);
-        if (rc != NL_OK) return rc;
-        if (n_pass == 0) {
-            const int m = nl_stack_last_mode(g->tiles[0]);
-            if (m != NL_ST_SIGMA && m != NL_ST_WINSOR_SIGMA) {
-                // same rule as nl_stack_find_sigmas; let it produce the message
-                return nl_stack_find_sigmas(g->tiles[0], mode, ref_loc, clip_perc_low, clip_perc_high, nullptr,
-                                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    const int64_t total = (int64_t)g->width * g->height * (int64_t)g->n_frames;
+    auto finish_all = [&](float *out) -> int {
+        if (out)
+            for (size_t t = 0; t < g->tiles.size(); t++) {
+                int rc = nl_stack_finish(g->tiles[t], out, nullptr, nullptr);
+                if (rc != NL_OK) return rc;
+            }
+        return NL_OK;
+    };
+    int m = mode;
+    if (m == NL_ST_AUTO) {                                        // stack.go:45-55
+        const int l = g->n_frames;
+        m = l >= 25 ? NL_ST_LINEAR_FIT : (l >= 15 ? NL_ST_WINSOR_SIGMA : (l >= 6 ? NL_ST_SIGMA : NL_ST_MEAN));
+    }
+    int64_t lo = 0, hi = 0;
+    int rc = NL_OK, n_pass = 0;
+    if (m == NL_ST_SIGMA || m == NL_ST_WINSOR_SIGMA) {
+        nl::SigmaBisection bis(clip_perc_low, clip_perc_high, total);
+        for (;;) {                                            // stackfindsigma.go:48-98
+            rc = nl_group_run(g, m, bis.low_mid, bis.high_mid, ref_loc, nullptr, &lo, &hi);
+            if (rc != NL_OK) return rc;
+            n_pass++;
+            if (bis.step(lo, hi)) {
+                if (clip_low) *clip_low = lo;
+                if (clip_high) *clip_high = hi;
+                if (sigma_low) *sigma_low = bis.low_mid;
+                if (sigma_high) *sigma_high = bis.high_mid;
+                if (passes) *passes = n_pass;
+                return finish_all(out_host);
             }
         }
+    }
+    // stackfindsigma.go:40-46, 101-170: Newton's method for the linear fit; the other modes "do not
+    // support sigmas" and are stacked once with 0, 0
+    const bool newton = m == NL_ST_LINEAR_FIT;
+    nl::SigmaNewton nw(clip_perc_low, total);
+    for (;;) {
+        rc = nl_group_run(g, m, newton ? nw.next_low() : 0.0f, newton ? nw.next_high() : 0.0f, ref_loc, nullptr, &lo, &hi);
+        if (rc != NL_OK) return rc;
         n_pass++;
-        if (bis.step(lo, hi)) {
-            if (clip_low) *clip_low = lo;
-            if (clip_high) *clip_high = hi;
-            if (sigma_low) *sigma_low = bis.low_mid;
-            if (sigma_high) *sigma_high = bis.high_mid;
-            if (passes) *passes = n_pass;
-            if (out_host)
-                for (size_t t = 0; t < g->tiles.size(); t++) {
-                    rc = nl_stack_finish(g->tiles[t], out_host, nullptr, nullptr);
-                    if (rc != NL_OK) return rc;
-                }
-            return NL_OK;
+        const int st = newton ? nw.step(lo, hi) : 1;
+        if (st == 0) continue;
+        if (st == 2) {
+            rc = nl_group_run(g, m, nw.sig_low, nw.sig_high, ref_loc, nullptr, nullptr, nullptr);
+            if (rc != NL_OK) return rc;
         }
+        if (clip_low) *clip_low = newton ? nw.base_lo : lo;
+        if (clip_high) *clip_high = newton ? nw.base_hi : hi;
+        if (sigma_low) *sigma_low = newton ? nw.sig_low : 0.0f;
+        if (sigma_high) *sigma_high = newton ? nw.sig_high : 0.0f;
+        if (passes) *passes = n_pass;
+        return finish_all(out_host);
     }
 }
 

@@ -75,6 +75,56 @@ struct SigmaBisection {
     }
 };
 
+// Newton's method of the goal-seek for the linear fit (spec: stackfindsigma.go:101-170), as a state
+// machine fed with the counters of one pass at a time.  The reference's quirks are kept: both high
+// deltas subtract the LOW target (:114, :155) and the loop counter advances by three per iteration.
+struct SigmaNewton {
+    float sig_low = 6.0f, sig_high = 6.0f;
+    const float epsilon = 0.005f;
+    float perc_low, total;
+    int i = 0, phase = 0;                 // phase 0: base pass, 1: sig_low + eps, 2: sig_high + eps
+    float delta_l = 0, delta_h = 0, new_low = 0;
+    int64_t base_lo = 0, base_hi = 0;     // counters of the last base pass (what the reference returns)
+    SigmaNewton(float clip_perc_low, int64_t total_samples) : perc_low(clip_perc_low), total((float)total_samples) {}
+    // sigmas of the pass to run next
+    float next_low() const { return phase == 1 ? sig_low + epsilon : sig_low; }
+    float next_high() const { return phase == 2 ? sig_high + epsilon : sig_high; }
+    // counters of that pass.  0: go on; 1: done, the pass just run was the base pass; 2: done, but
+    // the result image has to be re-made with (sig_low, sig_high) -- a probe pass overwrote it
+    int step(int64_t clip_low, int64_t clip_high)
+    {
+        if (phase == 0) {
+            base_lo = clip_low; base_hi = clip_high;
+            const float pl = (float)clip_low * 100.0f / total, ph = (float)clip_high * 100.0f / total;
+            delta_l = pl - perc_low;
+            delta_h = ph - perc_low;                             // sic
+            const int li = (int)(100 * delta_l + 0.5f), hi = (int)(100 * delta_h + 0.5f);
+            if ((li == 0 && hi == 0) || i >= 20) return 1;
+            i++; phase = 1;
+            return 0;
+        }
+        if (phase == 1) {
+            const float d2 = (float)clip_low * 100.0f / total - perc_low;
+            const float diff = (d2 - delta_l) / epsilon;
+            if (diff == 0) return 2;
+            new_low = sig_low - delta_l / diff;
+            if (new_low < 0.1f) new_low = 0.1f;
+            if (new_low > 20) new_low = 20;
+            i++; phase = 2;
+            return 0;
+        }
+        const float d3 = (float)clip_high * 100.0f / total - perc_low;      // sic
+        const float diff = (d3 - delta_h) / epsilon;
+        if (diff == 0) return 2;
+        float new_high = sig_high - delta_h / diff;
+        if (new_high < 0.1f) new_high = 0.1f;
+        if (new_high > 20) new_high = 20;
+        sig_low = new_low; sig_high = new_high;
+        i++; phase = 0;
+        return 0;
+    }
+};
+
 // ---- stack_exact.hip ----
 // Picks lanes-per-wave and LDS bytes for the exact kernel; -1 if it cannot fit.
 int exact_plan(int mode, bool weighted, int n_frames, int n_pad, int max_lanes, int *lanes,
@@ -171,5 +221,7 @@ hipError_t launch_noise(const float *data, int width, int height, double *partia
                         int blocks, hipStream_t stream);
 hipError_t launch_median3x3(const float *in, float *out, int width, int height,
                             hipStream_t stream);
+constexpr int kMedianMaskMax = 32;
+hipError_t launch_median_mask(const float *in, float *out, int64_t n, const int *mask, int len, hipStream_t stream);
 
 }  // namespace nl

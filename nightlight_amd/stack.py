@@ -378,3 +378,14 @@ def median_filter_3x3(image, width, height, device=0):
     capi.check(lib.nl_median_filter_3x3(capi.fptr(src), capi.fptr(dst), int(width), int(height),
                                         int(device)))
     return dst
+
+
+def median_filter_mask(data, mask, device=0):
+    """MedianFilter (ops/pre/badpixels.go:54-77): out[i] = median of data[i + mask[j]] inside the data."""
+    lib = capi.load()
+    src = np.ascontiguousarray(data, dtype=np.float32).reshape(-1)
+    m = np.ascontiguousarray(mask, dtype=np.int32)
+    dst = np.empty_like(src)
+    capi.check(lib.nl_median_filter_mask(capi.fptr(src), capi.fptr(dst), src.size,
+                                         m.ctypes.data_as(C.POINTER(C.c_int32)), m.size, int(device)))
+    return dst

@@ -262,6 +262,56 @@ float nlo_median_f32(float *a, int n)
     return nlo_qselect_median_f32(a, n);
 }
 
+/* gather.go:26-38.  NOTE the reference takes the median of the WHOLE buffer (len(mask) values),
+ * not of the `num` gathered ones: where part of the neighbourhood falls outside the data the tail
+ * of the buffer still holds what earlier calls left there (permuted by their quickselects). */
+float nlo_gather_and_median(const float *data, int64_t n, int32_t index, const int32_t *mask, int mask_len,
+                            float *buffer)
+{
+    int num = 0;
+    for (int j = 0; j < mask_len; j++) {
+        int32_t io = index + mask[j];
+        if (io >= 0 && (int64_t)io < n) buffer[num++] = data[io];
+    }
+    return nlo_median_f32(buffer, mask_len);
+}
+
+/* ops/pre/badpixels.go:54-77 MedianFilter, as ONE goroutine walking 0..n-1 with one buffer
+ * (the reference splits the range over NumCPU goroutines, each with a fresh zeroed buffer).
+ * full[i] = 1 where the whole neighbourhood lies inside the data, i.e. where the result does
+ * not depend on the buffer's history. */
+void nlo_median_filter_mask(float *out, const float *data, int64_t n, const int32_t *mask, int mask_len,
+                            unsigned char *full)
+{
+    float *buffer = (float *)calloc((size_t)(mask_len > 0 ? mask_len : 1), sizeof(float));
+    for (int64_t i = 0; i < n; i++) {
+        int ok = 1;
+        for (int j = 0; j < mask_len; j++) {
+            int64_t io = i + mask[j];
+            if (io < 0 || io >= n) ok = 0;
+        }
+        if (full) full[i] = (unsigned char)ok;
+        out[i] = nlo_gather_and_median(data, n, (int32_t)i, mask, mask_len, buffer);
+    }
+    free(buffer);
+}
+
+/* star/findstars.go:187-200 CreateMask: offsets of a disc of the given radius */
+int nlo_create_mask(int32_t width, float radius, int32_t *mask, int cap)
+{
+    int cnt = 0;
+    int32_t rad = (int32_t)radius;
+    for (int32_t y = -rad; y <= rad; y++)
+        for (int32_t x = -rad; x <= rad; x++) {
+            float dist = (float)sqrt((double)(y * y + x * x));
+            if (dist <= radius + 1e-8f) {
+                if (cnt < cap) mask[cnt] = y * width + x;
+                cnt++;
+            }
+        }
+    return cnt;
+}
+
 /* median3x3.go:26-77 : interior = median of 3x3, border rows/cols copied */
 void nlo_median_filter_3x3(float *out, const float *data, int64_t n, int32_t width)
 {
@@ -822,6 +872,66 @@ int nlo_find_sigmas_bisect(int mode, const float *const *lights, const float *we
         if (delta_h > 0) { high_left = high_mid; high_mid = 0.5f * (high_left + high_right); }
         else if (delta_h < 0) { high_right = high_mid; high_mid = 0.5f * (high_left + high_right); }
     }
+}
+
+/* stackfindsigma.go:101-170 (commented-out spec): Newton's method on both sigmas for the
+ * linear fit.  Restated WITH the reference's quirks: deltaH and deltaH3 subtract the LOW
+ * target (:114, :155), and the loop counter advances by three per iteration (the body's two
+ * i++ plus the for statement's), so the "i>=20" test fires at the 8th base evaluation.
+ * Returns the number of stack passes made; res / counters are those of the last BASE pass. */
+int nlo_find_sigmas_newton(int mode, const float *const *lights, const float *weights,
+                           int n_frames, int64_t npix, float ref_loc,
+                           float clip_perc_low, float clip_perc_high, int num_cpu,
+                           float *res, int64_t *clip_low, int64_t *clip_high,
+                           float *sigma_low, float *sigma_high)
+{
+    (void)clip_perc_high;                                /* never read by the reference either */
+    float sig_low = 6.0f, sig_high = 6.0f;
+    const float epsilon = 0.005f;
+    const float total = (float)(npix * (int64_t)n_frames);
+    float *scratch = (float *)malloc(sizeof(float) * (size_t)npix);
+    int passes = 0;
+    for (int i = 0;; i++) {
+        int64_t c_lo = 0, c_hi = 0;
+        nlo_stack_apply(mode, lights, weights, n_frames, npix, ref_loc, sig_low, sig_high, num_cpu, res, &c_lo, &c_hi, NULL);
+        passes++;
+        float perc_l = (float)c_lo * 100.0f / total;
+        float perc_h = (float)c_hi * 100.0f / total;
+        float delta_l = perc_l - clip_perc_low;
+        float delta_h = perc_h - clip_perc_low;          /* sic, :114 */
+        int delta_li = (int)(100 * delta_l + 0.5f);
+        int delta_hi = (int)(100 * delta_h + 0.5f);
+        *clip_low = c_lo; *clip_high = c_hi;
+        *sigma_low = sig_low; *sigma_high = sig_high;
+        if ((delta_li == 0 && delta_hi == 0) || i >= 20) break;
+
+        i++;
+        int64_t c_lo2 = 0, c_hi2 = 0;
+        nlo_stack_apply(mode, lights, weights, n_frames, npix, ref_loc, sig_low + epsilon, sig_high, num_cpu, scratch, &c_lo2, &c_hi2, NULL);
+        passes++;
+        float perc_l2 = (float)c_lo2 * 100.0f / total;
+        float delta_l2 = perc_l2 - clip_perc_low;
+        float delta_l_diff = (delta_l2 - delta_l) / epsilon;
+        if (delta_l_diff == 0) break;
+        float new_low = sig_low - delta_l / delta_l_diff;
+        if (new_low < 0.1f) new_low = 0.1f;
+        if (new_low > 20) new_low = 20;
+
+        i++;
+        int64_t c_lo3 = 0, c_hi3 = 0;
+        nlo_stack_apply(mode, lights, weights, n_frames, npix, ref_loc, sig_low, sig_high + epsilon, num_cpu, scratch, &c_lo3, &c_hi3, NULL);
+        passes++;
+        float perc_h3 = (float)c_hi3 * 100.0f / total;
+        float delta_h3 = perc_h3 - clip_perc_low;        /* sic, :155 */
+        float delta_h_diff = (delta_h3 - delta_h) / epsilon;
+        if (delta_h_diff == 0) break;
+        float new_high = sig_high - delta_h / delta_h_diff;
+        if (new_high < 0.1f) new_high = 0.1f;
+        if (new_high > 20) new_high = 20;
+        sig_low = new_low; sig_high = new_high;
+    }
+    free(scratch);
+    return passes;
 }
 
 

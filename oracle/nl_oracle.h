@@ -86,6 +86,12 @@ float  nlo_estimate_noise(const float *data, int64_t n, int32_t width);
 /* ---- internal/median/median3x3.go ---- */
 float  nlo_median9(float *a);                                                 /* :85-110 */
 float  nlo_median_f32(float *a, int n);                                       /* :115-119 */
+/* internal/median/gather.go:26-38, ops/pre/badpixels.go:54-77, star/findstars.go:187-200 */
+float  nlo_gather_and_median(const float *data, int64_t n, int32_t index, const int32_t *mask, int mask_len,
+                             float *buffer);
+void   nlo_median_filter_mask(float *out, const float *data, int64_t n, const int32_t *mask, int mask_len,
+                              unsigned char *full);
+int    nlo_create_mask(int32_t width, float radius, int32_t *mask, int cap);
 void   nlo_median_filter_3x3(float *out, const float *data, int64_t n, int32_t width); /* :26-77 */
 
 /* ---- internal/ops/stack/stack.go : the nine per-pixel stackers ----
@@ -138,6 +144,12 @@ void nlo_stack_incremental_finalize(float *stack, int64_t npix, float weight_sum
  *      internal/ops/stack/stackfindsigma.go:48-98 (bisection) ----
  * Runs repeated nlo_stack_apply; returns number of stack passes made. */
 int  nlo_find_sigmas_bisect(int mode, const float *const *lights, const float *weights,
+                            int n_frames, int64_t npix, float ref_loc,
+                            float clip_perc_low, float clip_perc_high, int num_cpu,
+                            float *res, int64_t *clip_low, int64_t *clip_high,
+                            float *sigma_low, float *sigma_high);
+/* stackfindsigma.go:101-170 (Newton's method, the linear-fit branch of :40-41), quirks kept */
+int  nlo_find_sigmas_newton(int mode, const float *const *lights, const float *weights,
                             int n_frames, int64_t npix, float ref_loc,
                             float clip_perc_low, float clip_perc_high, int num_cpu,
                             float *res, int64_t *clip_low, int64_t *clip_high,

@@ -74,6 +74,11 @@ def lib():
         L.nlo_median9.restype = C.c_float
         L.nlo_median_f32.argtypes = [_f32p, C.c_int]
         L.nlo_median_f32.restype = C.c_float
+        _i32p = C.POINTER(C.c_int32)
+        L.nlo_median_filter_mask.argtypes = [_f32p, _f32p, C.c_int64, _i32p, C.c_int, C.POINTER(C.c_ubyte)]
+        L.nlo_median_filter_mask.restype = None
+        L.nlo_create_mask.argtypes = [C.c_int32, C.c_float, _i32p, C.c_int]
+        L.nlo_create_mask.restype = C.c_int
         L.nlo_median_filter_3x3.argtypes = [_f32p, _f32p, C.c_int64, C.c_int32]
         L.nlo_median_filter_3x3.restype = None
         L.nlo_auto_select_mode.argtypes = [C.c_int]
@@ -104,6 +109,8 @@ def lib():
                                              C.c_float, C.c_float, C.c_int, _f32p, _i64p, _i64p,
                                              _f32p, _f32p]
         L.nlo_find_sigmas_bisect.restype = C.c_int
+        L.nlo_find_sigmas_newton.argtypes = L.nlo_find_sigmas_bisect.argtypes
+        L.nlo_find_sigmas_newton.restype = C.c_int
     return _lib
 
 
@@ -186,6 +193,30 @@ def median9(a):
     return np.float32(lib().nlo_median9(_fp(a)))
 
 
+def median_f32(a):
+    a = _f32(a).copy()
+    return np.float32(lib().nlo_median_f32(_fp(a), a.size))
+
+
+def create_mask(width, radius):
+    """star/findstars.go:187-200."""
+    m = np.zeros(256, np.int32)
+    n = lib().nlo_create_mask(int(width), float(radius), m.ctypes.data_as(C.POINTER(C.c_int32)), m.size)
+    return m[:n].copy()
+
+
+def median_filter_mask(data, mask):
+    """MedianFilter (badpixels.go:54-77) walked by one goroutine; returns (out, full) where full marks
+    the pixels whose whole neighbourhood lies inside the data (result independent of call history)."""
+    data = _f32(data).reshape(-1)
+    mask = np.ascontiguousarray(mask, np.int32)
+    out = np.empty_like(data)
+    full = np.zeros(data.size, np.uint8)
+    lib().nlo_median_filter_mask(_fp(out), _fp(data), data.size, mask.ctypes.data_as(C.POINTER(C.c_int32)),
+                                 mask.size, full.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return out, full.astype(bool)
+
+
 def median_filter_3x3(data, width):
     data = _f32(data).reshape(-1)
     out = np.empty_like(data)
@@ -239,8 +270,14 @@ def stack_incremental_finalize(stack, weight_sum):
     return stack
 
 
+def find_sigmas_newton(mode, frames, clip_perc_low, clip_perc_high, weights=None, ref_loc=0.0, num_cpu=1):
+    """stackfindsigma.go:101-170; same return tuple as find_sigmas_bisect."""
+    return find_sigmas_bisect(mode, frames, clip_perc_low, clip_perc_high, weights, ref_loc, num_cpu,
+                              _fn="nlo_find_sigmas_newton")
+
+
 def find_sigmas_bisect(mode, frames, clip_perc_low, clip_perc_high, weights=None,
-                       ref_loc=0.0, num_cpu=1):
+                       ref_loc=0.0, num_cpu=1, _fn="nlo_find_sigmas_bisect"):
     keep, ptrs = _frame_ptrs(frames)
     n = len(keep)
     npix = keep[0].size
@@ -251,7 +288,7 @@ def find_sigmas_bisect(mode, frames, clip_perc_low, clip_perc_high, weights=None
     if weights is not None:
         weights = _f32(weights)
         wp = _fp(weights)
-    passes = lib().nlo_find_sigmas_bisect(int(mode), ptrs, wp, n, npix, C.c_float(ref_loc),
+    passes = getattr(lib(), _fn)(int(mode), ptrs, wp, n, npix, C.c_float(ref_loc),
                                           C.c_float(clip_perc_low), C.c_float(clip_perc_high),
                                           int(num_cpu), _fp(res), C.byref(cl), C.byref(ch),
                                           C.byref(sl), C.byref(sh))

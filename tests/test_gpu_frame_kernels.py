@@ -301,3 +301,38 @@ def test_download_rows(nl):
         for bad in ((n, 0, 1), (-2, 0, 1), (0, rows, 1), (0, -1, 1), (0, 0, rows + 1), (0, 3, 0)):
             with pytest.raises(capi.NlError):
                 st.download_rows(*bad)
+
+
+# ---- A16: MedianFloat32 / GatherAndMedian / MedianFilter ---------------------------------
+
+@pytest.mark.parametrize("radius", [1.0, 1.5, 2.0, 2.5])
+@pytest.mark.parametrize("width,height", [(64, 16), (211, 37)])
+def test_median_filter_mask_matches_gather_and_median(nl, oracle, radius, width, height):
+    # star.CreateMask discs of 5 .. 21 offsets (findstars.go:187-200; 9 offsets at radius 1.5 take the
+    # reference's 9-value network).  Where the whole neighbourhood lies inside the data the reference's
+    # GatherAndMedian is history-free and the device must match it bit for bit; elsewhere the device
+    # returns the median of the values that exist (gather.go:37 reads stale buffer contents there).
+    img = natural_image(width, height, 55)
+    img[::7] = np.round(img[::7] / 64.0) * 64.0           # ties
+    mask = oracle.create_mask(width, radius)
+    assert mask.size in (5, 9, 13, 21)
+    got = nl.median_filter_mask(img, mask)
+    want, full = oracle.median_filter_mask(img, mask)
+    assert full.sum() == img.size - (int(mask.max()) - int(mask.min()))     # linear-index neighbourhoods
+    assert bits_equal(got[full], want[full]), "%d pixels differ" % np.count_nonzero(got[full] != want[full])
+    # edges: median of the existing neighbours, even counts averaged (qsort.go:68-82)
+    for i in np.flatnonzero(~full)[:: max(1, (~full).sum() // 200)]:
+        idx = i + mask
+        vals = np.sort(img[idx[(idx >= 0) & (idx < img.size)]])
+        k = vals.size // 2
+        ref = vals[k] if vals.size % 2 else np.float32(0.5) * (vals[k - 1] + vals[k])
+        assert got[i] == ref, (i, got[i], ref)
+
+
+def test_median_filter_mask_argument_errors(nl):
+    from nightlight_amd import capi
+    img = np.zeros(64, np.float32)
+    with pytest.raises(capi.NlError):
+        nl.median_filter_mask(img, np.arange(40, dtype=np.int32))          # more than 32 offsets
+    with pytest.raises(capi.NlError):
+        nl.median_filter_mask(img, np.zeros(0, np.int32))

@@ -554,3 +554,43 @@ def test_multi_lane_mad_129_to_512_frames(nl, oracle, n):
         got, gc, want, wc = run_both(nl, oracle, 4, frames, width, height, None, sl, sh, exact=False)
         assert gc == wc, "multi-lane mad n=%d clip counters %r vs oracle %r" % (n, gc, wc)
         assert close_values(got, want), "multi-lane mad n=%d: %s" % (n, describe_mismatch(got, want))
+
+
+def test_newton_goal_seek_for_the_linear_fit(nl, oracle):
+    # stackfindsigma.go:101-170 (the StLinearFit branch of FindSigmasAndStack): Newton steps from (6, 6)
+    # with probe passes at +0.005.  The linear-fit counters are exact, so the device takes the oracle's
+    # path pass for pass -- quirks included (high deltas against the LOW target, counter += 3)
+    width, height, n = 256, 64, 30
+    frames = make_frames(n, width, height, seed=9)
+    passes, ores, ocl, och, osl, osh = oracle.find_sigmas_newton(5, frames, 1.0, 1.0, num_cpu=8)
+    assert passes == 13                                   # several Newton iterations, not the zero-derivative exit
+    with nl.StackHandle(n, width, height) as st:
+        st.upload_frames(frames)
+        out, cl, ch, sl, sh, got_passes = st.find_sigmas(5, 1.0, 1.0)
+    assert (got_passes, cl, ch) == (passes, ocl, och)
+    assert (np.float32(sl), np.float32(sh)) == (osl, osh)
+    assert close_values(out, ores), describe_mismatch(out, ores)
+    # the same through the single-process multi-tile fan-out (host-summed counters)
+    with nl.StackGroup(n, width, height, devices=[0, 0, 0]) as g:
+        g.upload_frames(frames)
+        out, cl, ch, sl, sh, got_passes = g.find_sigmas(5, 1.0, 1.0)
+    assert (got_passes, cl, ch, np.float32(sl), np.float32(sh)) == (passes, ocl, och, osl, osh)
+    assert close_values(out, ores)
+    # zero derivative: a probe pass overwrote the result, which has to be re-made at (6, 6)
+    small = make_frames(30, 64, 16, seed=5)
+    passes, ores, ocl, och, osl, osh = oracle.find_sigmas_newton(5, small, 1.0, 1.0, num_cpu=2)
+    with nl.StackHandle(30, 64, 16) as st:
+        st.upload_frames(small)
+        out, cl, ch, sl, sh, got_passes = st.find_sigmas(5, 1.0, 1.0)
+    assert (got_passes, cl, ch, sl, sh) == (2, ocl, och, 6.0, 6.0) and close_values(out, ores)
+
+
+def test_goal_seek_on_modes_without_sigmas_stacks_once(nl, oracle):
+    # stackfindsigma.go:42-46: "does not support sigmas, proceeding with normal stack" -- Stack(..., 0, 0)
+    frames = make_frames(9, 64, 8, seed=3)
+    with nl.StackHandle(9, 64, 8) as st:
+        st.upload_frames(frames)
+        for mode in (0, 1):
+            out, cl, ch, sl, sh, passes = st.find_sigmas(mode, 1.0, 1.0)
+            rc, want, _, _, _ = oracle.stack_apply(mode, frames, None, 0.0, 0.0)
+            assert (passes, sl, sh) == (1, 0.0, 0.0) and same_values(out, want)

@@ -226,6 +226,21 @@ __device__ __forceinline__ void pick_pair(const float (&v)[NS], int idx, float &
     lower = lo;
 }
 
+// min / max as the instructions themselves: fminf / fmaxf put a canonicalising v_max_f32 x, x, x
+// in front of every operand that comes out of the (asm) sorting network.  No NaN reaches these.
+__device__ __forceinline__ float max_raw(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float min_raw(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // NaN -> +Inf, everything else unchanged: IEEE minNum(NaN, Inf) = Inf.  Written
 // as the instruction itself so that it stays ONE VALU op without a lane mask.
 __device__ __forceinline__ float nan_to_inf(float x)

@@ -226,6 +226,24 @@ void stack_mad_fast_kernel(StackArgs p, FastArgs q)
 //                pixel's own NaNs -- the high zone reserves no positions for them (a third
 //                fewer zone positions to mask, count and re-sum every clipping round); a lane
 //                whose NaNs leave no survivor in the high zone goes to the generic pass as before.
+#ifdef NL_ROUND_STATS
+// developer statistics (build with make EXTRA=-DNL_ROUND_STATS): [0] winsor rounds executed by waves,
+// [1] rounds lanes needed, [2] clip passes executed by waves, [3] clip passes lanes needed, [4] waves
+__device__ unsigned long long nl_dbg_rounds[8];
+extern "C" int nl_debug_round_stats(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nl_dbg_rounds), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(nl_dbg_rounds), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define NL_STAT(i, x) atomicAdd(&nl_dbg_rounds[i], (unsigned long long)(x))
+#else
+#define NL_STAT(i, x) ((void)0)
+#endif
+
 template <int NS, bool ZONAL, bool WINSOR, bool TIGHT>
 __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
 {
@@ -304,7 +322,12 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         // winsorization (stack.go:646-672) clamps at median -/+ 1.5 sigma: in the zonal
         // passes only sorted positions outside [WL, WH) are allowed to reach a clamp,
         // the inner half contributes these fixed sums
-        constexpr int WL = ZONAL ? (NS / 4 + 3) / 4 * 4 : 0, WH = ZONAL ? NS - WL - KP : NS;
+        // (the clamps sit at +-1.5 sigma: 6.7 % of a Gaussian column per side, 8.6 +- 2.8 samples of 128;
+        // a pixel with more goes to the replay through shape_ok)
+#ifndef NL_WINSOR_WL
+#define NL_WINSOR_WL(ns) ((ns) >= 112 ? 20 : ((ns) >= 80 ? 16 : ((ns) / 4 + 3) / 4 * 4))
+#endif
+        constexpr int WL = ZONAL ? NL_WINSOR_WL(NS) : 0, WH = ZONAL ? NS - WL - KP : NS;
         float d_in = 0.0f, q_in = 0.0f;
         if constexpr (ZONAL && WINSOR) {
             static_assert(WL >= ZL && WH <= ZH && (WL - ZL) % 4 == 0 && (WH - WL) % 4 == 0, "winsor zones");
@@ -325,7 +348,9 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         // bounds every survivor passed
         float amax = fmaxf(fabsf(v[0]), fabsf(pick<ZONAL ? ZH : 0, NS>(v, n - 1)));
 
+        if (ZONAL && lane == 0) NL_STAT(4, 1);
         while (__any(active)) {
+            if (ZONAL) { if (lane == 0) NL_STAT(2, 1); if (active) NL_STAT(3, 1); }
             // re-materialised per pass: otherwise the differences v[k] - c of every masked
             // position are hoisted out of the loop (one register each -- 128 in the generic pass;
             // the 24 of the zonal sigma pass are left alone)
@@ -408,37 +433,39 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                 const float inv_cnt = 1.0f / fcnt;
                 bool inner = active && !bail;
                 while (__any(inner)) {
+                    if (ZONAL) { if (lane == 0) NL_STAT(0, 1); if (inner) NL_STAT(1, 1); }
                     wi.next_clamp(median, xmin, xmax);
                     // variance of clamp(x, Lt, Ht) over the survivors (shifted moments) and its error bound
-                    auto clamped_variance = [&](const float Lt, const float Ht, float &wvar, float &werr) NL_INL {
+                    auto clamped_variance = [&](const float Lt, const float Ht, float &wvar, float &werr, float &wmean_c,
+                                                float &wrms) NL_INL {
                     float d0 = 0, d1 = 0, d2 = 0, d3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
                     if constexpr (ZONAL) {
                         // only the outer quarters of the sorted column can sit on a clamp
                         // (checked below); the inner half enters unclamped through d_in / q_in
                         static_range<0, ZL>([&](auto K) NL_INL {
                             constexpr int k = decltype(K)::value;
-                            const float e = (k >= a) ? fmaxf(v[k], Lt) - cz : 0.0f;
+                            const float e = (k >= a) ? max_raw(v[k], Lt) - cz : 0.0f;
                             d0 += e; q0 = __builtin_fmaf(e, e, q0);
                         });
                         static_chunks<0, (WL - ZL) / 4, 2>([&](auto K) NL_INL {
                             constexpr int k = ZL + 4 * decltype(K)::value;
-                            const float e0 = fmaxf(v[k], Lt) - cz, e1 = fmaxf(v[k + 1], Lt) - cz;
-                            const float e2 = fmaxf(v[k + 2], Lt) - cz, e3 = fmaxf(v[k + 3], Lt) - cz;
+                            const float e0 = max_raw(v[k], Lt) - cz, e1 = max_raw(v[k + 1], Lt) - cz;
+                            const float e2 = max_raw(v[k + 2], Lt) - cz, e3 = max_raw(v[k + 3], Lt) - cz;
                             d0 += e0; d1 += e1; d2 += e2; d3 += e3;
                             q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
                             q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
                         });
                         static_chunks<0, (ZH - WH) / 4, 2>([&](auto K) NL_INL {
                             constexpr int k = WH + 4 * decltype(K)::value;
-                            const float e0 = fminf(v[k], Ht) - cz, e1 = fminf(v[k + 1], Ht) - cz;
-                            const float e2 = fminf(v[k + 2], Ht) - cz, e3 = fminf(v[k + 3], Ht) - cz;
+                            const float e0 = min_raw(v[k], Ht) - cz, e1 = min_raw(v[k + 1], Ht) - cz;
+                            const float e2 = min_raw(v[k + 2], Ht) - cz, e3 = min_raw(v[k + 3], Ht) - cz;
                             d0 += e0; d1 += e1; d2 += e2; d3 += e3;
                             q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
                             q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
                         });
                         static_range<ZH, NS>([&](auto K) NL_INL {
                             constexpr int k = decltype(K)::value;
-                            const float e = (k < b) ? fminf(v[k], Ht) - cz : 0.0f;
+                            const float e = (k < b) ? min_raw(v[k], Ht) - cz : 0.0f;
                             d1 += e; q1 = __builtin_fmaf(e, e, q1);
                         });
                         d2 += d_in; q2 += q_in;
@@ -464,10 +491,57 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                     const float wb = wd * wd;
                     wvar = fmaxf(wa - wb, 0.0f);
                     werr = ((float)(NS / 2 + 34)) * kU * (wa + wb);
+                    wmean_c = wd;                                  // mean of the copy, minus c
+                    wrms = wa;                                     // E[(copy - c)^2]
                     };
-                    float var_t, err_t, var_l, err_l;
-                    clamped_variance(wi.Lp, wi.Hm, var_t, err_t);
-                    clamped_variance(wi.Lm, wi.Hp, var_l, err_l);
+                    float var_t, err_t, wd_t, wa_t;
+                    clamped_variance(wi.Lp, wi.Hm, var_t, err_t, wd_t, wa_t);
+                    // The loosest clamp (Lm, Hp) is not evaluated: with y = the copy at the tightest
+                    // clamp and z = the copy at the loosest, z - y = delta is non-zero only for the
+                    // n_lo samples below Lp (delta in [-(Lp-Lm), 0], y = Lp there) and the n_hi samples
+                    // above Hm (delta in [0, Hp-Hm], y = Hm), so
+                    //   var(z) = var(y) + 2 cov(y, delta) + var(delta)
+                    //         <= var(y) + [n_lo dL (2 (ybar-Lp) + dL) + n_hi dH (2 (Hm-ybar) + dH)] / cnt.
+                    // n_lo, n_hi only need upper bounds: the column is sorted, so testing every 4th
+                    // position (every 2nd, every one for the small networks) bounds them to +3.
+                    // (CS = 1 for the small networks: +3 on a handful of clamped samples would loosen the bound)
+                    constexpr int CS = NS >= 64 ? 4 : (NS >= 48 ? 2 : 1);
+                    int t_lo = 0, t_hi = 0;
+                    if constexpr (ZONAL) {
+                        static_range<0, WL / CS>([&](auto J) NL_INL {
+                            constexpr int k = CS * decltype(J)::value + CS - 1;
+                            const bool below = v[k] < wi.Lp;
+                            t_lo += ((k >= ZL || k >= a) && below) ? 1 : 0;
+                        });
+                        static_range<0, (NS - WH) / CS>([&](auto J) NL_INL {
+                            constexpr int k = WH + CS * decltype(J)::value;
+                            const bool above = v[k] > wi.Hm;
+                            t_hi += ((k < ZH || k < b) && above) ? 1 : 0;
+                        });
+                    } else {
+                        const int a5 = opaque(a);
+                        static_range<0, NS / CS>([&](auto J) NL_INL {
+                            constexpr int k = CS * decltype(J)::value;
+                            const bool in_lo = (unsigned)(k + CS - 1 - a5) < (unsigned)cnt;
+                            const bool in_hi = (unsigned)(k - a5) < (unsigned)cnt;
+                            t_lo += (in_lo && v[k + CS - 1] < wi.Lp) ? 1 : 0;
+                            t_hi += (in_hi && v[k] > wi.Hm) ? 1 : 0;
+                        });
+                    }
+                    float var_l, err_l;
+                    {
+                        const float n_lo = (float)min(CS * t_lo + CS - 1, cnt), n_hi = (float)min(CS * t_hi + CS - 1, cnt);
+                        const float dL = (wi.Lp - wi.Lm) * (1.0f + 2.0f * kU), dH = (wi.Hp - wi.Hm) * (1.0f + 2.0f * kU);
+                        // ybar = cz + wd_t, off by <= (NS/4+8) u mean|y-c| <= 3e-6 sqrt(E[(y-c)^2]) plus its own rounding
+                        const float ybar = cz + wd_t;
+                        const float slop = 4.0e-6f * __builtin_amdgcn_sqrtf(wa_t) + 4.0f * kU * fabsf(ybar) + 1.0e-30f;
+                        const float gL = fmaxf(ybar - wi.Lp, 0.0f) + slop, gH = fmaxf(wi.Hm - ybar, 0.0f) + slop;
+                        const float corr = (n_lo * (dL * (2.0f * gL + dL)) + n_hi * (dH * (2.0f * gH + dH))) * inv_cnt;
+                        // an infinite clamp width (first round: Lm = Lp = -Inf gives Inf - Inf) cannot occur:
+                        // both ends of an interval are finite or the same infinity -> NaN -> 0
+                        var_l = var_t + ((corr == corr) ? corr * 1.001f : 0.0f);
+                        err_l = err_t;
+                    }
                     // zonal: the inner half must be strictly inside every clamp of the interval
                     const bool shape_ok = !ZONAL || (v[WL] >= wi.Lp && v[WH - 1] <= wi.Hm);
                     wi.finish_round(var_t, err_t, var_l, err_l, eps_r, e_m, shape_ok, inner, bail);

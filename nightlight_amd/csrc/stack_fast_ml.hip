@@ -31,6 +31,22 @@ namespace nl {
 // time from the frame count, and the median is looked up over whole lanes.
 // Valid while more than LAST*128 + 8 samples are present.
 // (zonal sigma: the allocator lands one register above the 168 that let 3 waves share a SIMD)
+#ifdef NL_ROUND_STATS
+__device__ unsigned long long nl_dbg_rounds_ml[8];           // as nl_dbg_rounds in stack_fast.hip
+extern "C" int nl_debug_round_stats_ml(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nl_dbg_rounds_ml), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(nl_dbg_rounds_ml), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define NL_STAT(i, x) atomicAdd(&nl_dbg_rounds_ml[i], (unsigned long long)(x))
+#else
+#define NL_STAT(i, x) ((void)0)
+#endif
+
 template <int LPP, bool ZONAL, bool WINSOR, bool WIDE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZONAL ? (WINSOR ? 2 : 3) : 1, 8)))
 void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
@@ -61,7 +77,8 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
         if (listed) pix = on ? (int64_t)q.in_list[item] : 0;
 
         float v[NS];
-        const int n = ml_gather_sorted<LPP, NS, ZONAL && !WIDE>(p.frames, p.stride, N, on, pix, role, v);
+        // (winsorized: every lane fully sorted -- the clamped counts below sample every 8th rank)
+        const int n = ml_gather_sorted<LPP, NS, ZONAL && !WIDE && !WINSOR>(p.frames, p.stride, N, on, pix, role, v);
 
         bool to_exact = false;
         float res = p.ref_loc;
@@ -122,7 +139,9 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
             amax = fmaxf(fabsf(lowest), fabsf(highest));
         }
 
+        if (ZONAL && lane == 0) NL_STAT(4, 1);
         while (__any(active)) {
+            if (ZONAL) { if (lane == 0) NL_STAT(2, 1); if (active && role == 0) NL_STAT(3, 1); }
             // WIDE: re-materialised per pass, otherwise the 120 differences v[k] - c of the
             // wide zone are hoisted out of the loop and cost 120 registers
             float cz = c;
@@ -208,10 +227,12 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
                 const int a_loc = role == 0 ? a : (role > LAST ? NS : 0);
                 const int b_loc = role == LAST ? b - LAST * NS : (role > LAST ? 0 : NS);
                 while (__any(inner)) {
+                    if (ZONAL) { if (lane == 0) NL_STAT(0, 1); if (inner && role == 0) NL_STAT(1, 1); }
                     // (re-materialised per round: otherwise one lane mask per position is kept in SGPRs)
                     const int al = opaque(a_loc), bl = opaque(b_loc);
                     wi.next_clamp(median, xmin, xmax);
-                    auto clamped_variance = [&](const float Lt, const float Ht, float &wvar, float &werr) NL_INL {
+                    auto clamped_variance = [&](const float Lt, const float Ht, float &wvar, float &werr, float &wmean_c,
+                                                float &wrms) NL_INL {
                         float d0 = 0, d1 = 0, d2 = 0, d3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
                         if constexpr (ZONAL) {
                             static_range<0, ZL>([&](auto K) NL_INL {
@@ -256,10 +277,47 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
                         const float wb = wd * wd;
                         wvar = fmaxf(wa - wb, 0.0f);
                         werr = ((float)(NS / 2 + 48)) * kU * (wa + wb);
+                        wmean_c = wd;
+                        wrms = wa;
                     };
-                    float var_t, err_t, var_l, err_l;
-                    clamped_variance(wi.Lp, wi.Hm, var_t, err_t);
-                    clamped_variance(wi.Lm, wi.Hp, var_l, err_l);
+                    float var_t, err_t, wd_t, wa_t;
+                    clamped_variance(wi.Lp, wi.Hm, var_t, err_t, wd_t, wa_t);
+                    // loosest clamp (Lm, Hp): first-order bound from the number of clamped samples instead
+                    // of a second evaluation (see stack_fast.hip); every lane is fully sorted, so testing
+                    // every 8th rank bounds the counts to +7
+                    int t_lo = 0, t_hi = 0;
+                    if constexpr (ZONAL) {
+                        static_range<0, NS / 8>([&](auto J) NL_INL {
+                            constexpr int k = 8 * decltype(J)::value;
+                            const bool lo_in = (k + 7 >= ZL) || (k + 7 >= al);
+                            const bool hi_in = (k < NS - ZHS) || (k < bl);
+                            t_lo += (lo_in && v[k + 7] < wi.Lp) ? 1 : 0;
+                            t_hi += (hi_in && v[k] > wi.Hm) ? 1 : 0;
+                        });
+                        if (role > LAST) { t_lo = 0; t_hi = 0; }        // (WIDE) lanes of padding
+                    } else {
+                        const int a5 = opaque(a - role * NS);
+                        static_range<0, NS / 8>([&](auto J) NL_INL {
+                            constexpr int k = 8 * decltype(J)::value;
+                            const bool lo_in = (unsigned)(k + 7 - a5) < (unsigned)cnt;
+                            const bool hi_in = (unsigned)(k - a5) < (unsigned)cnt;
+                            t_lo += (lo_in && v[k + 7] < wi.Lp) ? 1 : 0;
+                            t_hi += (hi_in && v[k] > wi.Hm) ? 1 : 0;
+                        });
+                    }
+                    t_lo = quad_sum<LPP>(t_lo);
+                    t_hi = quad_sum<LPP>(t_hi);
+                    float var_l, err_l;
+                    {
+                        const float n_lo = (float)min(8 * t_lo + 7, cnt), n_hi = (float)min(8 * t_hi + 7, cnt);
+                        const float dL = (wi.Lp - wi.Lm) * (1.0f + 2.0f * kU), dH = (wi.Hp - wi.Hm) * (1.0f + 2.0f * kU);
+                        const float ybar = cz + wd_t;
+                        const float slop = 4.0e-6f * __builtin_amdgcn_sqrtf(wa_t) + 4.0f * kU * fabsf(ybar) + 1.0e-30f;
+                        const float gL = fmaxf(ybar - wi.Lp, 0.0f) + slop, gH = fmaxf(wi.Hm - ybar, 0.0f) + slop;
+                        const float corr = (n_lo * (dL * (2.0f * gL + dL)) + n_hi * (dH * (2.0f * gH + dH))) * inv_cnt;
+                        var_l = var_t + ((corr == corr) ? corr * 1.001f : 0.0f);
+                        err_l = err_t;
+                    }
                     wi.finish_round(var_t, err_t, var_l, err_l, eps_r, e_m, true, inner, bail);
                 }
                 s_min = wi.hull_lo;

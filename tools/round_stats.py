@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Developer probe: winsorization rounds / clip passes executed per wave vs needed per lane.
+Needs a library built with  make EXTRA=-DNL_ROUND_STATS  (stack_fast.hip / stack_fast_ml.hip)."""
+import ctypes
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nightlight_amd import StackHandle, capi
+
+mode = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+h = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+lib = ctypes.CDLL(capi.LIB_PATH)
+out = (ctypes.c_ulonglong * 8)()
+with StackHandle(n, 4096, h, device=0) as st:
+    st.fill_synthetic(seed=0x4E4C5354)
+    st.run(mode, 3.0, 3.0)
+    fn = lib.nl_debug_round_stats_ml if n > 128 else lib.nl_debug_round_stats
+    fn(out, 1)
+    st.run(mode, 3.0, 3.0)
+    fn(out, 1)
+    v = list(out)
+    waves = max(v[4], 1)
+    lanes = 4096 * h                      # pixels (multi-lane kernels count one lane per pixel)
+    print("mode %d n %d: kernel %s %.3f ms" % (mode, n, st.last_kernel_name, st.last_kernel_ms))
+    print("  waves %d; winsor rounds per wave %.2f, per lane %.2f; clip passes per wave %.2f, per lane %.2f"
+          % (waves, v[0] / waves, v[1] / lanes, v[2] / waves, v[3] / lanes))

@@ -48,11 +48,11 @@ __device__ __forceinline__ int quad_or(int x)
 }
 
 // in-lane half-cleaners of a bitonic merge: distances NS/2 ... 1, ascending
-template <int NS, int D>
+template <int NS, int D, int CH = 32>
 __device__ __forceinline__ void half_clean(float (&v)[NS])
 {
     if constexpr (D >= 1) {
-        static_chunks<0, NS / 2, 32>([&](auto T) NL_INL {
+        static_chunks<0, NS / 2, CH>([&](auto T) NL_INL {
             constexpr int t = decltype(T)::value;
             constexpr int i = ((t & ~(D - 1)) << 1) | (t & (D - 1));
             constexpr int l = i | D;
@@ -61,7 +61,7 @@ __device__ __forceinline__ void half_clean(float (&v)[NS])
             v[i] = lo;
             v[l] = hi;
         });
-        half_clean<NS, (D >> 1)>(v);
+        half_clean<NS, (D >> 1), CH>(v);
     }
 }
 
@@ -70,11 +70,11 @@ __device__ __forceinline__ void half_clean(float (&v)[NS])
 // other positions are only ever summed, so they merely have to hold the right
 // SET.  A half-cleaner block that cannot reach either end is skipped:
 // 224 instead of 448 compare-exchanges for NS = 128, KEEP = 16.
-template <int NS, int D, int KEEP>
+template <int NS, int D, int KEEP, int CH = 32>
 __device__ __forceinline__ void half_clean_ends(float (&v)[NS])
 {
     if constexpr (D >= 1) {
-        static_chunks<0, NS / 2, 32>([&](auto T) NL_INL {
+        static_chunks<0, NS / 2, CH>([&](auto T) NL_INL {
             constexpr int t = decltype(T)::value;
             constexpr int i = ((t & ~(D - 1)) << 1) | (t & (D - 1));
             constexpr int l = i | D;
@@ -86,7 +86,7 @@ __device__ __forceinline__ void half_clean_ends(float (&v)[NS])
                 v[l] = hi;
             }
         });
-        half_clean_ends<NS, (D >> 1), KEEP>(v);
+        half_clean_ends<NS, (D >> 1), KEEP, CH>(v);
     }
 }
 
@@ -145,22 +145,21 @@ __device__ __forceinline__ float pick_rank(const float (&v)[NS], int g, int role
 // Sort every lane's column and merge the LPP runs of a pixel: afterwards lane r holds the global
 // ranks [r*NS, r*NS+NS).  ENDS_ONLY: the last merge orders only the KEEP lowest / highest ranks
 // of every lane (see half_clean_ends).
-template <int LPP, int NS, bool ENDS_ONLY>
+template <int LPP, int NS, bool ENDS_ONLY, int KEEP = 16, int CH = 32>
 __device__ __forceinline__ void ml_sort_merge(float (&v)[NS], int role)
 {
     sort_network<NS>(v);
     // ---- merge the LPP sorted runs: lane r ends up with ranks [r*NS, r*NS+NS) ----
     // (zonal: the final half-cleaners only order the ends of each lane, see half_clean_ends)
-    constexpr int KEEP = 16;
     static_assert(kZone + kPadMax <= KEEP, "zones must lie inside the sorted ends");
     cross_stage<NS, kSwap1, true>(v, (role & 1) == 0);
-    if constexpr (ENDS_ONLY && LPP == 2) half_clean_ends<NS, NS / 2, KEEP>(v);
-    else                             half_clean<NS, NS / 2>(v);
+    if constexpr (ENDS_ONLY && LPP == 2) half_clean_ends<NS, NS / 2, KEEP, CH>(v);
+    else                             half_clean<NS, NS / 2, CH>(v);
     if constexpr (LPP == 4) {
         cross_stage<NS, kMirror, true>(v, role < 2);
         cross_stage<NS, kSwap1, false>(v, (role & 1) == 0);
-        if constexpr (ENDS_ONLY) half_clean_ends<NS, NS / 2, KEEP>(v);
-        else                 half_clean<NS, NS / 2>(v);
+        if constexpr (ENDS_ONLY) half_clean_ends<NS, NS / 2, KEEP, CH>(v);
+        else                 half_clean<NS, NS / 2, CH>(v);
     }
 }
 
@@ -168,7 +167,7 @@ __device__ __forceinline__ void ml_sort_merge(float (&v)[NS], int role)
 // lane's column and merge the runs: afterwards lane r holds global ranks [r*NS, r*NS+NS)
 // (+Inf for missing samples at the top).  Returns the number of valid samples of the pixel.
 // ENDS_ONLY: the last merge orders only the KEEP lowest / highest ranks of every lane.
-template <int LPP, int NS, bool ENDS_ONLY>
+template <int LPP, int NS, bool ENDS_ONLY, int KEEP = 16, int CH = 32>
 __device__ __forceinline__ int ml_gather_sorted(const float *frames, int64_t stride, int N, bool on, int64_t pix,
                                                 int role, float (&v)[NS])
 {
@@ -220,7 +219,7 @@ int nan_cnt = 0;
             });
         }
     }
-    ml_sort_merge<LPP, NS, ENDS_ONLY>(v, role);
+    ml_sort_merge<LPP, NS, ENDS_ONLY, KEEP, CH>(v, role);
     return quad_sum<LPP>(NS - nan_cnt);
 }
 

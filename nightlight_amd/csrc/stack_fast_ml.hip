@@ -18,6 +18,7 @@
 //
 // StackSigma: internal/ops/stack/stack.go:372-436.  HBM traffic: every sample is
 // read once; a wave instruction covers 64/LPP consecutive pixels of LPP frames.
+#include <cstdlib>
 #include <string>
 
 #include "fast_ml_common.hpp"
@@ -586,7 +587,7 @@ int fast_ml_supported(int mode, bool weighted, int n_frames, int64_t npix)
 
 template <int LPP, bool WINSOR, bool WIDE>
 static void launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
-                      hipEvent_t dominant_done, AfterDominant after, void *user)
+                      hipEvent_t dominant_done, AfterDominant after, void *user, const char **mlz_name)
 {
     const unsigned per_wg = 256 / LPP;
     const unsigned tile_blocks = (unsigned)((args.npix + per_wg - 1) / per_wg);
@@ -594,8 +595,13 @@ static void launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t 
     f.in_list = nullptr;
     f.in_count = nullptr;
     f.in_capacity = 0;
-    hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, true, WINSOR, WIDE>), dim3(tile_blocks), dim3(256), 0, stream,
-                       args, f);
+    if (!WIDE && mlz_name) {
+        // every position in use: the clipping rounds run on LDS columns (stack_fast_mlz.hip)
+        (void)launch_stack_sigma_mlz(args, f, stream, mlz_name, WINSOR);
+    } else {
+        hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, true, WINSOR, WIDE>), dim3(tile_blocks), dim3(256), 0, stream,
+                           args, f);
+    }
     if (dominant_done) (void)hipEventRecord(dominant_done, stream);
     if (after) after(user);
     f.in_list = fargs.gen_list;
@@ -621,12 +627,15 @@ static void launch_ml_variant(const StackArgs &args, const FastArgs &fargs, hipS
         "stack_sigma_ml_kernel<" + std::to_string(LPP) + ", true, true, false>",
         "stack_sigma_ml_kernel<" + std::to_string(LPP) + ", true, true, true>"};
     *name = names[(winsor ? 2 : 0) + (wide ? 1 : 0)].c_str();
+    // NL_MLZ=0 (developer switch) keeps the register-zone kernel for A/B measurements
+    static const bool mlz_on = [] { const char *e = getenv("NL_MLZ"); return !(e && e[0] == '0'); }();
+    const char **mlz_name = (!wide && mlz_on && fast_mlz_supported(winsor ? NL_ST_WINSOR_SIGMA : NL_ST_SIGMA, false, n)) ? name : nullptr;
     if (winsor) {
-        if (wide) launch_ml<LPP, true, true>(args, fargs, stream, dominant_done, after, user);
-        else      launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user);
+        if (wide) launch_ml<LPP, true, true>(args, fargs, stream, dominant_done, after, user, nullptr);
+        else      launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user, mlz_name);
     } else {
-        if (wide) launch_ml<LPP, false, true>(args, fargs, stream, dominant_done, after, user);
-        else      launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user);
+        if (wide) launch_ml<LPP, false, true>(args, fargs, stream, dominant_done, after, user, nullptr);
+        else      launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user, mlz_name);
     }
 }
 

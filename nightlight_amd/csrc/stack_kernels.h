@@ -147,6 +147,11 @@ hipError_t launch_stack_mad_fast(const StackArgs &args, const FastArgs &fargs, h
 // after_dominant(user) is called between the launch of the dominant (zonal) kernel and
 // the generic pass, so the caller can start work that only depends on the former
 typedef void (*AfterDominant)(void *user);
+// 249..256 / 505..512 frames: zonal sigma / winsorized sigma pass with the clipping rounds on LDS
+// columns (stack_fast_mlz.hip); hand-over lists as the other fast kernels
+int fast_mlz_supported(int mode, bool weighted, int n_frames);
+hipError_t launch_stack_sigma_mlz(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name,
+                                  bool winsor);
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
                                    const char **name, hipEvent_t dominant_done,
                                    bool winsor, AfterDominant after_dominant, void *user);

@@ -106,7 +106,7 @@ def test_c2_sigma_128x4096x4096(nl, oracle):
 def test_c3_tile_winsor_512x512x4096(nl, oracle):
     # BASELINE.json configs[2], one GPU's share: rows [1536, 2048) of 512 frames of 4096x4096; 4 GiB
     check_config(nl, oracle, 512, 4096, 4096, 1536, 512, mode=3, kappa=2.75, bit_exact=False,
-                 strip_rows=128, kernel_prefix="stack_sigma_ml_kernel<4", sample_blocks=8, oracle_strip_rows=4)
+                 strip_rows=128, kernel_prefix="stack_sigma_mlz_kernel<4", sample_blocks=8, oracle_strip_rows=4)
 
 
 def test_c4_linear_fit_128x4096x4096_noise_weighted(nl, oracle):
@@ -127,7 +127,7 @@ def test_c5_median_64x6000x4000(nl, oracle):
 def test_sigma_512x4096x4096(nl, oracle):
     # the north star's roofline target configuration; 32 GiB of frames in one buffer
     check_config(nl, oracle, 512, 4096, 4096, 0, 4096, mode=2, kappa=3.0, bit_exact=False,
-                 strip_rows=1024, kernel_prefix="stack_sigma_ml_kernel<4", sample_blocks=8, oracle_strip_rows=4)
+                 strip_rows=1024, kernel_prefix="stack_sigma_mlz_kernel<4", sample_blocks=8, oracle_strip_rows=4)
 
 
 def test_weighted_sigma_128x4096x4096(nl, oracle):

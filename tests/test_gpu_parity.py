@@ -161,6 +161,36 @@ def test_multi_lane_sigma_129_to_512_frames(nl, oracle, n, clean):
     assert close_values(got, want), "multi-lane sigma n=%d: %s" % (n, describe_mismatch(got, want))
 
 
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("n", [249, 252, 256, 505, 509, 512])
+@pytest.mark.parametrize("case", ["clean", "nan", "ties", "heavy", "tight"])
+def test_lds_column_kernels_249_256_and_505_512_frames(nl, oracle, mode, n, case):
+    # stack_fast_mlz.hip: clipping / winsorization rounds on LDS columns with walking pointers.
+    # "heavy": 6 % hot and 3 % cold outliers -- clips and clamps run to the ends of the columns
+    # (hand-over to the generic pass); "tight": kappa 1.2 / 1.0 clips a fifth of the samples;
+    # "ties": values quantised to 16 -- runs of equal samples across the pointers
+    width, height = 97, 11
+    kw = dict(nan_frac=0.0, nan_border=False, all_nan_patch=False)
+    sl, sh = 3.0, 2.5
+    if case == "nan":
+        kw = dict(nan_frac=0.01)
+    elif case == "ties":
+        kw = dict(nan_frac=0.002, ties=True)
+    elif case == "heavy":
+        kw = dict(nan_frac=0.0, nan_border=False, all_nan_patch=False, hot=0.06, cold=0.03)
+    elif case == "tight":
+        sl, sh = 1.2, 1.0
+    frames = make_frames(n, width, height, seed=900 + n + 7 * mode, **kw)
+    with nl.StackHandle(n, width, height) as st:
+        st.upload_frames(frames)
+        got, cl, ch = st.run(mode, sl, sh, 0.0)
+        assert st.last_kernel_name.startswith("stack_sigma_mlz_kernel<"), st.last_kernel_name
+    rc, want, wl, wh, _ = oracle.stack_apply(mode, frames, None, sl, sh, 0.0, num_cpu=4)
+    assert rc == 0
+    assert (cl, ch) == (wl, wh), "%s n=%d mode %d clip counters %r vs oracle %r" % (case, n, mode, (cl, ch), (wl, wh))
+    assert close_values(got, want), "%s n=%d mode %d: %s" % (case, n, mode, describe_mismatch(got, want))
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 7, 33, 64, 65, 128, 130, 300, 512])
 def test_wave_per_pixel_exact_replay_is_bit_exact(nl, oracle, n):
     # stack_exact_coop.hip: 64 lanes replay ONE pixel in the reference's order

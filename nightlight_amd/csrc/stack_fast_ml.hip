@@ -607,6 +607,13 @@ static void launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t 
     f.in_list = fargs.gen_list;
     f.in_count = fargs.gen_count;
     f.in_capacity = fargs.gen_capacity;
+    // generic pass over the hand-over list: whole columns in LDS (stack_fast_mlg.hip); NL_MLG=0 (developer
+    // switch) keeps the register version, which masks every position of every lane in every round
+    static const bool mlg_on = [] { const char *e = getenv("NL_MLG"); return !(e && e[0] == '0'); }();
+    if (mlg_on) {
+        (void)launch_stack_sigma_mlg(args, f, 4 * kGenericGrid, stream, WINSOR);
+        return;
+    }
     const unsigned gblocks = tile_blocks < kGenericGrid ? tile_blocks : kGenericGrid;
     hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, false, WINSOR, false>), dim3(gblocks), dim3(256), 0, stream,
                        args, f);

@@ -26,6 +26,22 @@
 
 namespace nl {
 
+#ifdef NL_ROUND_STATS
+__device__ unsigned long long nl_dbg_rounds_mlz[8];          // hand-over causes: [0] missing samples, [1] c2 >= 8, [2] d2 >= 8,
+extern "C" int nl_debug_round_stats_mlz(unsigned long long *out, int reset)     // [3] low zone, [4] high zone, [5] shape -> exact
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nl_dbg_rounds_mlz), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(nl_dbg_rounds_mlz), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define NL_STAT(i, x) atomicAdd(&nl_dbg_rounds_mlz[i], (unsigned long long)(x))
+#else
+#define NL_STAT(i, x) ((void)0)
+#endif
+
 namespace {
 
 template <int LPP>
@@ -37,6 +53,7 @@ struct MlzLayout {
     static constexpr int BLOCK = mlz_block<LPP>;
     static constexpr int PW = BLOCK / LPP;                      // pixels per workgroup = LDS row length (64)
     static constexpr int ZLC = 16, ZHC = 24;                    // alive window: a < ZLC, b > NT - ZHC
+    static constexpr int CR = WINSOR ? 16 : 8;                  // ranks read per side and pass for the clip decisions
     static constexpr int KL = WINSOR ? (LPP == 4 ? 64 : 32) : 24;          // low column : ranks [0, KL)
     static constexpr int KH = WINSOR ? (LPP == 4 ? 72 : 40) : 32;          // high column: ranks [NT-KH, NT)
     static constexpr int GL = KL / 4 + 1, GH = KH / 4 + 1;      // table entries
@@ -47,7 +64,7 @@ struct MlzLayout {
                          XW = SH2 + GH, ROWS = XW + MW;
     // roundings a term of the moment sums can see: fixed part (4 accumulators + quad adds), tables, assembly
     static constexpr int ROUNDINGS = (NS / 4 + 10 > KH + 4 ? NS / 4 + 10 : KH + 4) + 12;
-    static_assert(KL % 8 == 0 && KH % 8 == 0 && KL >= ZLC + 8 && KH >= ZHC + 8, "column sizes");
+    static_assert(KL % 8 == 0 && KH % 8 == 0 && KL >= ZLC + CR && KH >= ZHC + CR, "column sizes");
     static_assert(KL <= NS && KH <= NS, "a column comes from one lane");
 };
 
@@ -91,7 +108,7 @@ __global__ __launch_bounds__(mlz_block<LPP>) __attribute__((amdgpu_waves_per_eu(
 void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
 {
     using L = MlzLayout<LPP, WINSOR>;
-    constexpr int NS = L::NS, NT = L::NT, PW = L::PW, KL = L::KL, KH = L::KH;
+    constexpr int NS = L::NS, NT = L::NT, PW = L::PW, KL = L::KL, KH = L::KH, CR = L::CR;
     constexpr int LAST = LPP - 1, MIDR = LPP / 2 - 1;
     __shared__ float lds[L::ROWS * PW];
 
@@ -136,6 +153,7 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     bool active = on && n > 0;
     // the alive window must keep its ends inside the columns: at most 15 missing samples
     bool to_generic = active && !(n > NT - 16);
+    if (to_generic && role == 0) NL_STAT(0, 1);
     active = active && !to_generic;
     bool to_exact = false;
 
@@ -211,16 +229,17 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     while (__any(active)) {
         const int cnt = b - a;
         const float fcnt = (float)cnt;
-        const int al = min(max(a, 0), KL - 8);                       // (clamped for the address only)
-        const int bl = min(max(b - (NT - KH), 8), KH);               // local end of the alive part of the high column
-        // ---- reads: 8 ranks from each end of the alive window, the tables, the median ----
-        float xl[8], xh[8];
+        const int al = min(max(a, 0), KL - CR);                      // (clamped for the address only)
+        const int bl = min(max(b - (NT - KH), CR), KH);              // local end of the alive part of the high column
+        // ---- reads: CR ranks from each end of the alive window (xl[i] = rank a+i, xh[i] = rank b-1-i),
+        // the tables, the median ----
+        float xl[CR], xh[CR];
         {
             const float *pl = col + (L::XL + al) * PW;
-            const float *ph = col + (L::XH + bl - 8) * PW;
-            static_range<0, 8>([&](auto I) NL_INL {
+            const float *ph = col + (L::XH + bl - 1) * PW;
+            static_range<0, CR>([&](auto I) NL_INL {
                 xl[decltype(I)::value] = pl[decltype(I)::value * PW];
-                xh[decltype(I)::value] = ph[decltype(I)::value * PW];
+                xh[decltype(I)::value] = *(ph - decltype(I)::value * PW);
             });
         }
         const int ga = al >> 2, gb = bl >> 2;
@@ -242,9 +261,9 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
                 qz = __builtin_fmaf(e, e, qz);
             });
             const int nhp = bl & 3;                        // local 4 gb .. bl-1
-            static_range<5, 8>([&](auto I) NL_INL {
+            static_range<0, 3>([&](auto I) NL_INL {
                 constexpr int i = decltype(I)::value;
-                const float e = (i >= 8 - nhp) ? xh[i] - c : 0.0f;
+                const float e = (i < nhp) ? xh[i] - c : 0.0f;
                 dz += e;
                 qz = __builtin_fmaf(e, e, qz);
             });
@@ -258,7 +277,7 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         const float var = fmaxf(aa - bb, 0.0f);
 
         // ---- bracket the reference's stddev ----
-        const float amax = fmaxf(fabsf(xl[0]), fabsf(xh[7]));
+        const float amax = fmaxf(fabsf(xl[0]), fabsf(xh[0]));
         const float err_o = kErrF * kU * (aa + bb);
         const float eps_r = 1.02f * (fcnt + 8.0f) * kU;
         const float e_m = 1.02f * (fcnt + 2.0f) * kU * amax;
@@ -282,7 +301,7 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
             int jl = al, jh = bl;
             bool first = true;
             while (__any(inner)) {
-                wi.next_clamp(median, xl[0], xh[7]);
+                wi.next_clamp(median, xl[0], xh[0]);
                 if (first) {
                     // coarse start: every 8th rank of the columns
                     int t_lo = 0, t_hi = 0;
@@ -354,8 +373,10 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
                 }
                 // the clamps must stay inside the columns (and the ranks between the columns inside the clamps)
                 const bool shape_ok = jl <= KL - 8 && jh >= 8 && x_in_lo >= wi.Lp && x_in_hi <= wi.Hm;
+                if (inner && !shape_ok && role == 0) NL_STAT(5, 1);
                 wi.finish_round(var_t, err_t, var_l, err_t, eps_r, e_m, shape_ok, inner, bail);
             }
+            if (active && bail && role == 0) NL_STAT(wi.guard > 100 ? 7 : 6, 1);
             s_min = wi.hull_lo;
             s_max = wi.hull_hi;
         }
@@ -368,16 +389,22 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         const float lo_min = fminf(la, lb), lo_max = fmaxf(la, lb);
         const float hi_min = fminf(ha, hb), hi_max = fmaxf(ha, hb);
 
-        // ---- certain (c1, d1) and possible (c2, d2) clips among the 8 outermost survivors per side ----
+        // ---- certain (c1, d1) and possible (c2, d2) clips among the CR outermost survivors per side ----
         int c1 = 0, c2 = 0, d1 = 0, d2 = 0;
-        static_range<0, 8>([&](auto I) NL_INL {
+        static_range<0, CR>([&](auto I) NL_INL {
             constexpr int i = decltype(I)::value;
             c1 += (xl[i] < lo_min) ? 1 : 0;
             c2 += (xl[i] < lo_max) ? 1 : 0;
             d1 += (xh[i] > hi_max) ? 1 : 0;
             d2 += (xh[i] > hi_min) ? 1 : 0;
         });
-        if (active && (c2 >= 8 || d2 >= 8 || a + c2 >= L::ZLC || b - d2 <= NT - L::ZHC)) {
+        if (active && role == 0) {
+            if (c2 >= CR) NL_STAT(1, 1);
+            else if (d2 >= CR) NL_STAT(2, 1);
+            else if (a + c2 >= L::ZLC) NL_STAT(3, 1);
+            else if (b - d2 <= NT - L::ZHC) NL_STAT(4, 1);
+        }
+        if (active && (c2 >= CR || d2 >= CR || a + c2 >= L::ZLC || b - d2 <= NT - L::ZHC)) {
             to_generic = true;                 // more clips than the columns hold: generic pass, from scratch
             active = false;
         }

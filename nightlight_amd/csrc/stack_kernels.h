@@ -149,6 +149,9 @@ hipError_t launch_stack_mad_fast(const StackArgs &args, const FastArgs &fargs, h
 typedef void (*AfterDominant)(void *user);
 // 249..256 / 505..512 frames: zonal sigma / winsorized sigma pass with the clipping rounds on LDS
 // columns (stack_fast_mlz.hip); hand-over lists as the other fast kernels
+// generic pass of the multi-lane sigma / winsor kernels over fargs.in_list, whole columns in LDS (stack_fast_mlg.hip)
+hipError_t launch_stack_sigma_mlg(const StackArgs &args, const FastArgs &fargs, unsigned grid, hipStream_t stream,
+                                  bool winsor);
 int fast_mlz_supported(int mode, bool weighted, int n_frames);
 hipError_t launch_stack_sigma_mlz(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name,
                                   bool winsor);

@@ -15,7 +15,8 @@ out = (ctypes.c_ulonglong * 8)()
 with StackHandle(n, 4096, h, device=0) as st:
     st.fill_synthetic(seed=0x4E4C5354)
     st.run(mode, 3.0, 3.0)
-    fn = lib.nl_debug_round_stats_ml if n > 128 else lib.nl_debug_round_stats
+    name = "nl_debug_round_stats_ml" if n > 128 else "nl_debug_round_stats"
+    fn = getattr(lib, name) if hasattr(lib, name) else (lambda o, r: 0)
     fn(out, 1)
     st.run(mode, 3.0, 3.0)
     fn(out, 1)
@@ -25,3 +26,12 @@ with StackHandle(n, 4096, h, device=0) as st:
     print("mode %d n %d: kernel %s %.3f ms" % (mode, n, st.last_kernel_name, st.last_kernel_ms))
     print("  waves %d; winsor rounds per wave %.2f, per lane %.2f; clip passes per wave %.2f, per lane %.2f"
           % (waves, v[0] / waves, v[1] / lanes, v[2] / waves, v[3] / lanes))
+    if n > 128 and hasattr(lib, "nl_debug_round_stats_mlz"):
+        lib.nl_debug_round_stats_mlz(out, 1)
+        print("  LDS-column kernel hand-overs: missing %d, c2>=8 %d, d2>=8 %d, low zone %d, high zone %d; shape -> exact %d; winsor bail %d, guard>100 %d" % tuple(list(out)[:8]))
+    if n > 128 and hasattr(lib, "nl_debug_round_stats_mlg"):
+        lib.nl_debug_round_stats_mlg(out, 1)
+        g = list(out)
+        trips = max(g[4], 1)
+        print("  generic pass: %d wave trips; rounds per trip %.2f (lanes %d); passes per trip %.2f (lanes %d)"
+              % (trips, g[0] / trips, g[1], g[2] / trips, g[3]))

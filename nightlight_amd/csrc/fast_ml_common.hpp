@@ -153,13 +153,26 @@ __device__ __forceinline__ void ml_sort_merge(float (&v)[NS], int role)
     // (zonal: the final half-cleaners only order the ends of each lane, see half_clean_ends)
     static_assert(kZone + kPadMax <= KEEP, "zones must lie inside the sorted ends");
     cross_stage<NS, kSwap1, true>(v, (role & 1) == 0);
-    if constexpr (ENDS_ONLY && LPP == 2) half_clean_ends<NS, NS / 2, KEEP, CH>(v);
-    else                             half_clean<NS, NS / 2, CH>(v);
-    if constexpr (LPP == 4) {
-        cross_stage<NS, kMirror, true>(v, role < 2);
-        cross_stage<NS, kSwap1, false>(v, (role & 1) == 0);
-        if constexpr (ENDS_ONLY) half_clean_ends<NS, NS / 2, KEEP, CH>(v);
-        else                 half_clean<NS, NS / 2, CH>(v);
+    // the in-lane half-cleaners run as 2-/3-input operations too (FusedBitonic, sort_tables.inc: the
+    // 0-1 analysis over bitonic inputs fuses 30 % of the instructions away)
+    if constexpr (NS == 128 && (KEEP == 16 || KEEP == 32)) {
+        if constexpr (ENDS_ONLY && LPP == 2) run_network<FusedBitonic<NS, KEEP>, NS>(v);
+        else                             run_network<FusedBitonic<NS, 0>, NS>(v);
+        if constexpr (LPP == 4) {
+            cross_stage<NS, kMirror, true>(v, role < 2);
+            cross_stage<NS, kSwap1, false>(v, (role & 1) == 0);
+            if constexpr (ENDS_ONLY) run_network<FusedBitonic<NS, KEEP>, NS>(v);
+            else                 run_network<FusedBitonic<NS, 0>, NS>(v);
+        }
+    } else {
+        if constexpr (ENDS_ONLY && LPP == 2) half_clean_ends<NS, NS / 2, KEEP, CH>(v);
+        else                             half_clean<NS, NS / 2, CH>(v);
+        if constexpr (LPP == 4) {
+            cross_stage<NS, kMirror, true>(v, role < 2);
+            cross_stage<NS, kSwap1, false>(v, (role & 1) == 0);
+            if constexpr (ENDS_ONLY) half_clean_ends<NS, NS / 2, KEEP, CH>(v);
+            else                 half_clean<NS, NS / 2, CH>(v);
+        }
     }
 }
 

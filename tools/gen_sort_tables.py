@@ -91,16 +91,59 @@ def block_domain(p):
     return w
 
 
+def bitonic(ns, keep_ends):
+    """Comparators of the half-cleaner cascade that sorts a bitonic sequence of ns elements
+    (distances ns/2 .. 1), as half_clean / half_clean_ends (fast_ml_common.hpp) emit them;
+    keep_ends > 0: only the blocks that can reach the keep_ends lowest / highest positions."""
+    ces = []
+    d = ns // 2
+    while d >= 1:
+        for t in range(ns // 2):
+            i = ((t & ~(d - 1)) << 1) | (t & (d - 1))
+            blk = i & ~(2 * d - 1)
+            if not keep_ends or blk < keep_ends or blk + 2 * d > ns - keep_ends:
+                ces.append((ns // 2, i, i | d))          # one "level": the block is the whole sequence
+        d //= 2
+    return ces
+
+
+def bitonic_domain(ns):
+    """zero-one bitonic sequences 0^a 1^b 0^c and 1^a 0^b 1^c, one bitset per wire"""
+    w = [0] * ns
+    idx = 0
+    for a in range(ns + 1):
+        for b in range(ns + 1 - a):
+            for k in range(a, a + b):
+                w[k] |= 1 << idx
+            idx += 1
+            for k in range(0, a):
+                w[k] |= 1 << idx
+            for k in range(a + b, ns):
+                w[k] |= 1 << idx
+            idx += 1
+    return w
+
+
 def build(ns, e):
     """-> (ops, out_slot, n_slots, n_ce); ops = (kind, dst, a, b, c)"""
     ces = oem(ns)
     keep = prune(ns, ces, e) if any(e) else [True] * len(ces)
+    return build_net(ns, ces, keep, block_domain)
+
+
+def build_bitonic(ns, keep_ends):
+    ces = bitonic(ns, keep_ends)
+    dom = bitonic_domain(ns)
+    return build_net(ns, ces, [True] * len(ces), lambda p: dom)
+
+
+def build_net(ns, ces, keep, domain_of):
     # ---- nodes with the 0-1 images of their inputs, producer links inside a merge level ----
     nodes = []
     cur_p, last, state, dom = None, {}, {}, None
     for idx, (p, lo, hi) in enumerate(ces):
         if p != cur_p:
-            cur_p, last, state, dom = p, {}, {}, block_domain(p)
+            cur_p, last, state, dom = p, {}, {}, domain_of(p)
         blk = lo // (2 * p) * (2 * p)
         for w in (lo, hi):
             if w not in state:
@@ -283,6 +326,32 @@ def verify(ns, e, ops, out, n_slots, trials=600, seed=1):
         assert np.array_equal(np.sort(y[:, a:b], axis=1), ref[:, a:b]), (ns, e, "set", a, b)
 
 
+def verify_bitonic(ns, keep_ends, ops, out, n_slots, trials=400, seed=3):
+    rng = np.random.default_rng(seed + ns + keep_ends)
+    rows = []
+    for kind in range(3):
+        x = rng.standard_normal((trials, ns))
+        if kind == 1:
+            x = rng.integers(0, 5, (trials, ns)).astype(np.float64)            # ties
+        if kind == 2:
+            x[:, ns - 5:] = np.inf                                              # pads
+        cut = rng.integers(0, ns + 1, trials)
+        for r in range(trials):
+            up = np.sort(x[r, :cut[r]])
+            dn = np.sort(x[r, cut[r]:])[::-1]
+            seq = np.concatenate([up, dn])                                      # ascending, then descending
+            rows.append(np.roll(seq, rng.integers(0, ns)) if r % 3 == 0 else (seq if r % 3 == 1 else seq[::-1]))
+    x = np.array(rows, dtype=np.float32)
+    y = simulate(ops, out, n_slots, x)
+    ref = np.sort(x, axis=1)
+    k = keep_ends if keep_ends else ns // 2
+    assert np.array_equal(y[:, :k], ref[:, :k]) and np.array_equal(y[:, ns - k:], ref[:, ns - k:]), (ns, keep_ends)
+    assert np.array_equal(np.sort(y, axis=1), ref), (ns, keep_ends, "set")
+
+
+BITONIC = ((128, 0), (128, 16), (128, 32))       # (size, KEEP): the merges of the multi-lane kernels
+
+
 def variants():
     v = []
     for ns in SIZES:
@@ -307,6 +376,28 @@ def render():
         verify(ns, e, ops, out, n_slots)
         summary.append((ns, e, n_ce, len(ops), n_slots))
         lines.append("template <> struct FusedNet<%d, %d, %d, %d, %d> {" % ((ns,) + e))
+        lines.append("    static constexpr int kCount = %d, kSlots = %d, kComparators = %d;" % (len(ops), n_slots, n_ce))
+        lines.append("    static constexpr FusedOp kOps[%d] = {" % len(ops))
+        row = []
+        for op in ops:
+            row.append("{%d,%d,%d,%d,%d}" % op)
+            if len(row) == 8:
+                lines.append("        " + ",".join(row) + ",")
+                row = []
+        if row:
+            lines.append("        " + ",".join(row) + ",")
+        lines.append("    };")
+        lines.append("    static constexpr short kOut[%d] = {%s};" % (ns, ",".join(str(s) for s in out)))
+        lines.append("};")
+    lines.append("")
+    lines.append("// half-cleaner cascades of the cross-lane bitonic merges (fast_ml_common.hpp): inputs are bitonic")
+    lines.append("// sequences; KEEP > 0: only the KEEP lowest / highest positions end up ordered")
+    lines.append("template <int NS, int KEEP> struct FusedBitonic;")
+    for ns, keep_ends in BITONIC:
+        ops, out, n_slots, n_ce = build_bitonic(ns, keep_ends)
+        verify_bitonic(ns, keep_ends, ops, out, n_slots)
+        summary.append((ns, ("bitonic", keep_ends), n_ce, len(ops), n_slots))
+        lines.append("template <> struct FusedBitonic<%d, %d> {" % (ns, keep_ends))
         lines.append("    static constexpr int kCount = %d, kSlots = %d, kComparators = %d;" % (len(ops), n_slots, n_ce))
         lines.append("    static constexpr FusedOp kOps[%d] = {" % len(ops))
         row = []

@@ -636,13 +636,18 @@ static void launch_ml_variant(const StackArgs &args, const FastArgs &fargs, hipS
     *name = names[(winsor ? 2 : 0) + (wide ? 1 : 0)].c_str();
     // NL_MLZ=0 (developer switch) keeps the register-zone kernel for A/B measurements
     static const bool mlz_on = [] { const char *e = getenv("NL_MLZ"); return !(e && e[0] == '0'); }();
-    const char **mlz_name = (!wide && mlz_on && fast_mlz_supported(winsor ? NL_ST_WINSOR_SIGMA : NL_ST_SIGMA, false, n)) ? name : nullptr;
+    const char **mlz_name = (mlz_on && fast_mlz_supported(winsor ? NL_ST_WINSOR_SIGMA : NL_ST_SIGMA, false, n)) ? name : nullptr;
+    if (mlz_name) {            // every frame count 129..512: LDS-column kernel of its class (stack_fast_mlz.hip)
+        if (winsor) launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user, mlz_name);
+        else        launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user, mlz_name);
+        return;
+    }
     if (winsor) {
         if (wide) launch_ml<LPP, true, true>(args, fargs, stream, dominant_done, after, user, nullptr);
-        else      launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user, mlz_name);
+        else      launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user, nullptr);
     } else {
         if (wide) launch_ml<LPP, false, true>(args, fargs, stream, dominant_done, after, user, nullptr);
-        else      launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user, mlz_name);
+        else      launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user, nullptr);
     }
 }
 

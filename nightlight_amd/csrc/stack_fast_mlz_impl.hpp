@@ -1,0 +1,502 @@
+// stack_fast_mlz_impl.hpp -- sigma / winsorized sigma clipping for 129..512 frames (2 or 4 lanes
+// per pixel): the clipping rounds run on COLUMNS IN LDS instead of on the register column.
+// Included by stack_fast_mlz_*.hip, which instantiate the kernel for their share of the frame-count
+// classes: the kernel is compiled once per NTOP = frame count rounded up to a multiple of 16, so
+// that the ranks it copies to LDS (the top of the column sits in the middle of a lane unless the
+// stack fills its lanes) are compile-time register indices.
+//
+// stack_fast_ml.hip re-sums and re-counts its zones with static register indices, so every
+// round costs a pass over all the positions any lane of the wave might need (and every lane of
+// a pixel executes it).  Here the sort and the merge are the same, but afterwards each pixel
+// writes to LDS, once,
+//   * its KL lowest and KH highest ranks (the only samples a clip or a clamp can reach),
+//   * suffix sums of (x-c) and (x-c)^2 over those columns, accumulated from the inner end
+//     outwards at every 4th position (so an outlier never enters a sum it is not part of),
+//   * the window of ranks the median can occupy,
+// and keeps only the moments of everything in between (never clipped, never clamped).  A
+// round is then a handful of per-lane LDS reads at data-dependent positions -- [slot][pixel]
+// layout, conflict-free -- plus scalar work: the alive window [a, b) and the clamp positions
+// are pointers that walk along the sorted columns, the sums come from the tables.  The cost of
+// a round no longer depends on the frame count.
+//
+// Exactness is as in stack_fast.hip / DESIGN.md section 5: every decision is taken on a
+// rigorous interval around the reference's fp32 value, undecidable pixels go to the exact
+// replay, pixels whose clips or clamps leave the columns go to the generic pass.
+// StackSigma: stack.go:372-436, StackWinsorSigma: stack.go:611-705.
+#pragma once
+#include <string>
+
+#include "fast_ml_common.hpp"
+
+namespace nl {
+
+#ifdef NL_ROUND_STATS
+__device__ unsigned long long nl_dbg_rounds_mlz[8];          // hand-over causes: [0] missing samples, [1] c2 >= 8, [2] d2 >= 8,
+extern "C" int nl_debug_round_stats_mlz(unsigned long long *out, int reset)     // [3] low zone, [4] high zone, [5] shape -> exact
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nl_dbg_rounds_mlz), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(nl_dbg_rounds_mlz), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define NL_STAT(i, x) atomicAdd(&nl_dbg_rounds_mlz[i], (unsigned long long)(x))
+#else
+#define NL_STAT(i, x) ((void)0)
+#endif
+
+namespace {
+
+template <int LPP>
+constexpr int mlz_block = LPP == 2 ? 128 : 256;     // threads per workgroup
+
+// NTOP: ranks in use (the frame count rounded up to a multiple of 16; NT for a stack that fills its lanes)
+template <int LPP, bool WINSOR, int NTOP>
+struct MlzLayout {
+    static constexpr int NS = kMlNS, NT = NS * LPP;
+    static constexpr bool FULL = NTOP == NT;                    // the columns sit at the ends of lanes
+    static constexpr int BLOCK = mlz_block<LPP>;
+    static constexpr int PW = BLOCK / LPP;                      // pixels per workgroup = LDS row length (64)
+    // alive window: a < ZLC, b > NTOP - ZHC; up to PADS missing samples (frames short of NTOP + NaNs)
+    static constexpr int ZLC = 16, ZHC = FULL ? 24 : 32, PADS = FULL ? 15 : 23;
+    static constexpr int CR = WINSOR ? 16 : 8;                  // ranks read per side and pass for the clip decisions
+    static constexpr int KL = WINSOR ? (LPP == 4 ? 64 : 32) : 24;          // low column : ranks [0, KL)
+    static constexpr int KH = (WINSOR ? (LPP == 4 ? 72 : 40) : 32) + (FULL ? 0 : 8);   // high column: ranks [NTOP-KH, NTOP)
+    static constexpr int GL = KL / 4 + 1, GH = KH / 4 + 1;      // table entries
+    // median window: kk = a + (b-a)/2 and kk-1 over all a < ZLC, b > NTOP - ZHC
+    static constexpr int TOPW = ZHC / 2 + 2, BOTW = ZLC / 2 + 2, MW = TOPW + BOTW;
+    static constexpr int W0 = NTOP / 2 - TOPW;                  // rank of window slot 0
+    static constexpr int H0 = NTOP - KH;                        // rank of high-column slot 0
+    // LDS rows, one float per pixel each
+    static constexpr int XL = 0, XH = XL + KL, SL1 = XH + KH, SL2 = SL1 + GL, SH1 = SL2 + GL, SH2 = SH1 + GH,
+                         XW = SH2 + GH, ROWS = XW + MW;
+    // roundings a term of the moment sums can see: fixed part (4 accumulators + quad adds), tables, assembly
+    static constexpr int ROUNDINGS = (NS / 4 + 10 > KH + 4 ? NS / 4 + 10 : KH + 4) + 12;
+    static_assert(NTOP % 16 == 0 && NTOP > NT / 2 && NTOP <= NT, "frame-count class");
+    static_assert(KL % 8 == 0 && KH % 8 == 0 && KL >= ZLC + CR && KH >= ZHC + CR, "column sizes");
+    static_assert(KL <= NS && KL <= H0 && W0 >= KL && W0 + MW <= H0 + KH, "columns and window inside the ranks in use");
+};
+
+// the pixel's lane `R`, in every lane of the pixel
+template <int LPP, int R>
+__device__ __forceinline__ int quad_bcast(int x)
+{
+    if constexpr (LPP == 2) return dpp_i<R == 0 ? 0xA0 : 0xF5>(x);            // quad_perm [0,0,2,2] / [1,1,3,3]
+    else return dpp_i<R == 0 ? 0x00 : (R == 1 ? 0x55 : (R == 2 ? 0xAA : 0xFF))>(x);
+}
+
+// LDS operations of one wave complete in order; the clobber keeps the compiler from moving
+// loads of other lanes' stores across this point
+__device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// sum of (v[k]-c) and (v[k]-c)^2 over k in [B, E), four accumulators
+template <int B, int E, int NS>
+__device__ __forceinline__ void seg_moments(const float (&v)[NS], float c, float &d, float &q)
+{
+    float d0 = 0, d1 = 0, d2 = 0, d3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    constexpr int M = (E - B) / 4;
+    static_chunks<0, M, 4>([&](auto K) NL_INL {
+        constexpr int k = B + 4 * decltype(K)::value;
+        const float e0 = v[k] - c, e1 = v[k + 1] - c, e2 = v[k + 2] - c, e3 = v[k + 3] - c;
+        d0 += e0; d1 += e1; d2 += e2; d3 += e3;
+        q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
+        q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
+    });
+    static_range<B + 4 * M, E>([&](auto K) NL_INL {
+        const float e = v[decltype(K)::value] - c;
+        d0 += e; q0 = __builtin_fmaf(e, e, q0);
+    });
+    d = (d0 + d1) + (d2 + d3);
+    q = (q0 + q1) + (q2 + q3);
+}
+
+}  // namespace
+
+template <int LPP, bool WINSOR, int NTOP>
+__global__ __launch_bounds__(mlz_block<LPP>) __attribute__((amdgpu_waves_per_eu(WINSOR ? 2 : 3, 8)))
+void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
+{
+    using L = MlzLayout<LPP, WINSOR, NTOP>;
+    constexpr int NS = L::NS, PW = L::PW, KL = L::KL, KH = L::KH, CR = L::CR, H0 = L::H0, W0 = L::W0;
+    __shared__ float lds[L::ROWS * PW];
+
+    const int lane = threadIdx.x & 63;
+    const int role = threadIdx.x % LPP;
+    float *col = lds + threadIdx.x / LPP;                  // element r of this pixel: col[r * PW]
+
+    int c_lo_total = 0, c_hi_total = 0;
+    const int64_t pix = (int64_t)blockIdx.x * PW + threadIdx.x / LPP;
+    const bool on = pix < p.npix;
+    int N = p.n_frames;
+    float v[NS];
+    // a stack that fills its lanes: the last merge orders the 32 lowest / highest ranks of every lane
+    // (columns of the plain sigma kernel, median window); the winsorized columns are longer, and the
+    // columns of a shorter stack sit inside the lanes: full merge
+    const int n = ml_gather_sorted<LPP, NS, L::FULL && !WINSOR, 32>(p.frames, p.stride, N, on, pix, role, v);
+
+    // ---- columns and median window to LDS ----
+    // (no divergent branches while the column is in registers -- they cost the compiler's register
+    // allocation over a hundred spills: the owning lane's value is broadcast inside the pixel's quad
+    // and every lane of the pixel stores it, same value to the same address)
+    auto bcast_f = [](auto R, float x) NL_INL {
+        return __int_as_float(quad_bcast<LPP, decltype(R)::value>(__float_as_int(x)));
+    };
+    static_range<0, KL>([&](auto K) NL_INL {
+        constexpr int k = decltype(K)::value;
+        col[(L::XL + k) * PW] = bcast_f(std::integral_constant<int, 0>{}, v[k]);
+    });
+    static_range<0, KH>([&](auto K) NL_INL {                          // rank H0 + k: lane rank / NS, register rank % NS
+        constexpr int k = decltype(K)::value, r = H0 + k;
+        col[(L::XH + k) * PW] = bcast_f(std::integral_constant<int, r / NS>{}, v[r % NS]);
+    });
+    static_range<0, L::MW>([&](auto K) NL_INL {
+        constexpr int k = decltype(K)::value, r = W0 + k;
+        col[(L::XW + k) * PW] = bcast_f(std::integral_constant<int, r / NS>{}, v[r % NS]);
+    });
+    lds_settle();
+
+    bool active = on && n > 0;
+    // the alive window must keep its ends inside the columns: at most PADS missing samples
+    bool to_generic = active && !(n > NTOP - 1 - L::PADS);
+    if (to_generic && role == 0) NL_STAT(0, 1);
+    active = active && !to_generic;
+    bool to_exact = false;
+
+    // shift c = first-pass median (any value near the bulk works)
+    const float c = col[(L::XW + min(max((n >> 1) - W0, 0), L::MW - 1)) * PW];
+
+    // ---- tables: sums from the inner end of each column outwards, every 4th position ----
+    // (read back from LDS: the high column of a stack that does not fill its lanes spans two lanes;
+    // every lane of the pixel runs the same chain and stores the same values)
+    {
+        float s1 = 0.0f, s2 = 0.0f;
+        col[(L::SL1 + KL / 4) * PW] = 0.0f;
+        col[(L::SL2 + KL / 4) * PW] = 0.0f;
+        static_range<0, KL / 4>([&](auto G) NL_INL {
+            constexpr int g = KL / 4 - 1 - decltype(G)::value;
+            static_range<0, 4>([&](auto U) NL_INL {
+                const float e = col[(L::XL + 4 * g + 3 - decltype(U)::value) * PW] - c;
+                s1 += e;
+                s2 = __builtin_fmaf(e, e, s2);
+            });
+            col[(L::SL1 + g) * PW] = s1;                   // sum over k >= 4g
+            col[(L::SL2 + g) * PW] = s2;
+        });
+    }
+    {
+        float s1 = 0.0f, s2 = 0.0f;
+        col[(L::SH1 + 0) * PW] = 0.0f;
+        col[(L::SH2 + 0) * PW] = 0.0f;
+        static_range<0, KH / 4>([&](auto G) NL_INL {
+            constexpr int g = decltype(G)::value;
+            static_range<0, 4>([&](auto U) NL_INL {
+                const float e = col[(L::XH + 4 * g + decltype(U)::value) * PW] - c;
+                s1 += e;
+                s2 = __builtin_fmaf(e, e, s2);
+            });
+            // sum over local t < 4(g+1); missing samples (+Inf) only reach entries that are never read (4g' <= b)
+            col[(L::SH1 + g + 1) * PW] = s1;
+            col[(L::SH2 + g + 1) * PW] = s2;
+        });
+    }
+
+    // ---- moments of the ranks between the columns (never clipped, never clamped) ----
+    // blocks of 8 registers; a block of lane `role` counts if its ranks lie in [KL, H0) (both multiples of 8):
+    // the rest is a column, or padding above the ranks in use
+    float d_fix, q_fix;
+    {
+        float da[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qa[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int off = role * NS - KL;
+        static_chunks<0, NS / 8, 2>([&](auto J) NL_INL {
+            constexpr int j = decltype(J)::value;
+            float d0 = 0.0f, d1 = 0.0f, q0 = 0.0f, q1 = 0.0f;
+            static_range<0, 4>([&](auto U) NL_INL {
+                constexpr int k = 8 * j + 2 * decltype(U)::value;
+                const float e0 = v[k] - c, e1 = v[k + 1] - c;
+                d0 += e0; d1 += e1;
+                q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
+            });
+            const bool inc = (unsigned)(8 * j + off) < (unsigned)(H0 - KL);
+            da[j & 3] += inc ? d0 + d1 : 0.0f;
+            qa[j & 3] += inc ? q0 + q1 : 0.0f;
+        });
+        d_fix = quad_sum<LPP>((da[0] + da[1]) + (da[2] + da[3]));
+        q_fix = quad_sum<LPP>((qa[0] + qa[1]) + (qa[2] + qa[3]));
+    }
+    // rank KL (first above the low column) and rank H0-1 (last below the high column)
+    float x_in_lo, x_in_hi;
+    {
+        x_in_lo = bcast_f(std::integral_constant<int, KL / NS>{}, v[KL % NS]);
+        x_in_hi = bcast_f(std::integral_constant<int, (H0 - 1) / NS>{}, v[(H0 - 1) % NS]);
+    }
+    lds_settle();
+
+    float res = p.ref_loc;
+    int c_lo = 0, c_hi = 0;
+    int a = 0, b = n;                                      // survivors = sorted ranks [a, b)
+    constexpr float kErrF = (float)(2 * L::ROUNDINGS + 8);
+
+    while (__any(active)) {
+        const int cnt = b - a;
+        const float fcnt = (float)cnt;
+        const int al = min(max(a, 0), KL - CR);                      // (clamped for the address only)
+        const int bl = min(max(b - H0, CR), KH);              // local end of the alive part of the high column
+        // ---- reads: CR ranks from each end of the alive window (xl[i] = rank a+i, xh[i] = rank b-1-i),
+        // the tables, the median ----
+        float xl[CR], xh[CR];
+        {
+            const float *pl = col + (L::XL + al) * PW;
+            const float *ph = col + (L::XH + bl - 1) * PW;
+            static_range<0, CR>([&](auto I) NL_INL {
+                xl[decltype(I)::value] = pl[decltype(I)::value * PW];
+                xh[decltype(I)::value] = *(ph - decltype(I)::value * PW);
+            });
+        }
+        const int ga = al >> 2, gb = bl >> 2;
+        const float sl1 = col[(L::SL1 + ga + 1) * PW], sl2 = col[(L::SL2 + ga + 1) * PW];
+        const float sh1 = col[(L::SH1 + gb) * PW], sh2 = col[(L::SH2 + gb) * PW];
+        const int kk = a + (cnt >> 1);
+        const int wi0 = min(max(kk - W0, 1), L::MW - 1);
+        const float upper = col[(L::XW + wi0) * PW], lower = col[(L::XW + wi0 - 1) * PW];
+        const float median = (cnt & 1) ? upper : 0.5f * (lower + upper);       // qsort.go:68-82
+
+        // ---- moments of the survivors: fixed part + tables + the partial groups at a and b ----
+        float dz = 0.0f, qz = 0.0f;
+        {
+            const int nlp = 4 - (al & 3);                  // ranks al .. 4(ga+1)-1
+            static_range<0, 4>([&](auto I) NL_INL {
+                constexpr int i = decltype(I)::value;
+                const float e = (i < nlp) ? xl[i] - c : 0.0f;
+                dz += e;
+                qz = __builtin_fmaf(e, e, qz);
+            });
+            const int nhp = bl & 3;                        // local 4 gb .. bl-1
+            static_range<0, 3>([&](auto I) NL_INL {
+                constexpr int i = decltype(I)::value;
+                const float e = (i < nhp) ? xh[i] - c : 0.0f;
+                dz += e;
+                qz = __builtin_fmaf(e, e, qz);
+            });
+        }
+        const float dsum = (d_fix + dz) + (sl1 + sh1);
+        const float qsum = (q_fix + qz) + (sl2 + sh2);
+        const float delta = dsum / fcnt;                   // mean~ - c
+        const float m = c + delta;
+        const float aa = qsum / fcnt;                      // E[(x-c)^2]~
+        const float bb = delta * delta;
+        const float var = fmaxf(aa - bb, 0.0f);
+
+        // ---- bracket the reference's stddev ----
+        const float amax = fmaxf(fabsf(xl[0]), fabsf(xh[0]));
+        const float err_o = kErrF * kU * (aa + bb);
+        const float eps_r = 1.02f * (fcnt + 8.0f) * kU;
+        const float e_m = 1.02f * (fcnt + 2.0f) * kU * amax;
+        const float v_up = var + err_o;
+        const float v_dn = fmaxf(var - err_o, 0.0f);
+        const float v_hi = v_up + v_up * eps_r + e_m * e_m;
+        const float v_lo = fmaxf(v_dn - v_dn * eps_r, 0.0f);
+        float s_max = __fsqrt_rn(v_hi) * (1.0f + 4.0f * kU);
+        float s_min = __fsqrt_rn(v_lo) * (1.0f - 4.0f * kU);
+        bool bail = !(v_hi < 3.0e38f);
+
+        if constexpr (WINSOR) {
+            // ---- winsorized stddev (stack.go:646-672) as an interval, WinsorInterval in fast_common.hpp ----
+            // jl = first rank of the low column that is not below the (tightest) low clamp Lp,
+            // jh = local end of the ranks of the high column that are not above the high clamp Hm:
+            // both clamps only tighten inside one loop, so the pointers only move inwards
+            WinsorInterval wi;
+            wi.start(s_min, s_max);
+            const float inv_cnt = 1.0f / fcnt;
+            bool inner = active && !bail;
+            int jl = al, jh = bl;
+            bool first = true;
+            while (__any(inner)) {
+                wi.next_clamp(median, xl[0], xh[0]);
+                if (first) {
+                    // coarse start: every 8th rank of the columns
+                    int t_lo = 0, t_hi = 0;
+                    static_range<0, KL / 8>([&](auto G) NL_INL {
+                        t_lo += (col[(L::XL + 8 * decltype(G)::value + 7) * PW] < wi.Lp) ? 1 : 0;
+                    });
+                    static_range<0, KH / 8>([&](auto G) NL_INL {
+                        t_hi += (col[(L::XH + 8 * decltype(G)::value) * PW] > wi.Hm) ? 1 : 0;
+                    });
+                    jl = max(jl, 8 * t_lo);
+                    jh = min(jh, KH - 8 * t_hi);
+                    first = false;
+                }
+                // walk: 8 candidates per step and side
+                bool more = inner;
+                while (__any(more)) {
+                    const int jlc = min(jl, KL - 8), jhc = max(jh, 8);
+                    const float *pl = col + (L::XL + jlc) * PW;
+                    const float *ph = col + (L::XH + jhc - 8) * PW;
+                    int up = 0, dn = 0;
+                    static_range<0, 8>([&](auto I) NL_INL {
+                        up += (pl[decltype(I)::value * PW] < wi.Lp) ? 1 : 0;
+                        dn += (ph[decltype(I)::value * PW] > wi.Hm) ? 1 : 0;
+                    });
+                    if (more) {
+                        jl = jlc + up;
+                        jh = jhc - dn;
+                        // a pointer at the inner end of its column: the shape test below hands the pixel over
+                        more = (up == 8 && jl <= KL - 8) || (dn == 8 && jh >= 8);
+                    }
+                }
+                // the clamped copy's moments: clamped ranks [a, jl) and local [jh, bl), unclamped the rest
+                const int jlc = min(jl, KL - 4), jhc = max(jh, 4);
+                const int gj = jlc >> 2, gh = jhc >> 2;
+                float dp = 0.0f, qp = 0.0f;
+                {
+                    const float *pl = col + (L::XL + jlc) * PW;
+                    const float *ph = col + (L::XH + jhc - 4) * PW;
+                    const int nlp = 4 - (jlc & 3), nhp = jhc & 3;
+                    static_range<0, 4>([&](auto I) NL_INL {
+                        constexpr int i = decltype(I)::value;
+                        const float e = (i < nlp) ? pl[i * PW] - c : 0.0f;
+                        dp += e; qp = __builtin_fmaf(e, e, qp);
+                        const float f = (i >= 4 - nhp) ? ph[i * PW] - c : 0.0f;
+                        dp += f; qp = __builtin_fmaf(f, f, qp);
+                    });
+                }
+                const float tl1 = col[(L::SL1 + gj + 1) * PW], tl2 = col[(L::SL2 + gj + 1) * PW];
+                const float th1 = col[(L::SH1 + gh) * PW], th2 = col[(L::SH2 + gh) * PW];
+                const float n_lo = (float)(jl - a), n_hi = (float)(bl - jh);
+                const float eL = wi.Lp - c, eH = wi.Hm - c;               // max(x, Lp) - c of a clamped sample
+                const float dcl = n_lo * eL + n_hi * eH;
+                const float qcl = n_lo * (eL * eL) + n_hi * (eH * eH);
+                const float wd = (((d_fix + dp) + (tl1 + th1)) + dcl) * inv_cnt;
+                const float wa = (((q_fix + qp) + (tl2 + th2)) + qcl) * inv_cnt;
+                const float wb = wd * wd;
+                const float var_t = fmaxf(wa - wb, 0.0f);
+                const float err_t = (kErrF + 8.0f) * kU * (wa + wb);
+                // loosest clamp (Lm, Hp): first-order bound, see stack_fast.hip -- the counts are exact here
+                float var_l;
+                {
+                    const float dL = (wi.Lp - wi.Lm) * (1.0f + 2.0f * kU), dH = (wi.Hp - wi.Hm) * (1.0f + 2.0f * kU);
+                    const float ybar = c + wd;
+                    // ybar is off by <= gamma_R mean|y-c| <= gamma_R sqrt(E[(y-c)^2]) plus its own rounding
+                    const float slop = (float)(L::ROUNDINGS + 8) * kU * 1.01f * __builtin_amdgcn_sqrtf(wa) + 4.0f * kU * fabsf(ybar) + 1.0e-30f;
+                    const float gL = fmaxf(ybar - wi.Lp, 0.0f) + slop, gH = fmaxf(wi.Hm - ybar, 0.0f) + slop;
+                    const float corr = (n_lo * (dL * (2.0f * gL + dL)) + n_hi * (dH * (2.0f * gH + dH))) * inv_cnt;
+                    var_l = var_t + ((corr == corr) ? corr * 1.001f : 0.0f);
+                }
+                // the clamps must stay inside the columns (and the ranks between the columns inside the clamps)
+                const bool shape_ok = jl <= KL - 8 && jh >= 8 && x_in_lo >= wi.Lp && x_in_hi <= wi.Hm;
+                if (inner && !shape_ok && role == 0) NL_STAT(5, 1);
+                wi.finish_round(var_t, err_t, var_l, err_t, eps_r, e_m, shape_ok, inner, bail);
+            }
+            if (active && bail && role == 0) NL_STAT(wi.guard > 100 ? 7 : 6, 1);
+            s_min = wi.hull_lo;
+            s_max = wi.hull_hi;
+        }
+
+        // ---- the reference's bound expressions (stack.go:408-409) at both ends of the interval ----
+        const float tl0 = __fmul_rn(p.sig_lo, s_min), tl1 = __fmul_rn(p.sig_lo, s_max);
+        const float th0 = __fmul_rn(p.sig_hi, s_min), th1 = __fmul_rn(p.sig_hi, s_max);
+        const float la = __fsub_rn(median, tl0), lb = __fsub_rn(median, tl1);
+        const float ha = __fadd_rn(median, th0), hb = __fadd_rn(median, th1);
+        const float lo_min = fminf(la, lb), lo_max = fmaxf(la, lb);
+        const float hi_min = fminf(ha, hb), hi_max = fmaxf(ha, hb);
+
+        // ---- certain (c1, d1) and possible (c2, d2) clips among the CR outermost survivors per side ----
+        int c1 = 0, c2 = 0, d1 = 0, d2 = 0;
+        static_range<0, CR>([&](auto I) NL_INL {
+            constexpr int i = decltype(I)::value;
+            c1 += (xl[i] < lo_min) ? 1 : 0;
+            c2 += (xl[i] < lo_max) ? 1 : 0;
+            d1 += (xh[i] > hi_max) ? 1 : 0;
+            d2 += (xh[i] > hi_min) ? 1 : 0;
+        });
+        if (active && role == 0) {
+            if (c2 >= CR) NL_STAT(1, 1);
+            else if (d2 >= CR) NL_STAT(2, 1);
+            else if (a + c2 >= L::ZLC) NL_STAT(3, 1);
+            else if (b - d2 <= NTOP - L::ZHC) NL_STAT(4, 1);
+        }
+        if (active && (c2 >= CR || d2 >= CR || a + c2 >= L::ZLC || b - d2 <= NTOP - L::ZHC)) {
+            to_generic = true;                 // more clips than the columns hold: generic pass, from scratch
+            active = false;
+        }
+        if (active) {
+            bail |= (c1 != c2) || (d1 != d2) || (lo_max > hi_min && (c1 + d1) > 0);
+            if (bail) {
+                to_exact = true;
+                active = false;
+            } else {
+                c_lo += c1;
+                c_hi += d1;
+                a += c1;
+                b -= d1;
+                if ((c1 + d1) == 0 || (b - a) <= 1) {      // stack.go:427-430: the mean BEFORE this pass
+                    res = m;
+                    active = false;
+                }
+            }
+        }
+    }
+
+    // one lane per pixel reports
+    const bool rep = on && role == 0;
+    if (rep && !to_generic && !to_exact) {
+        p.out[pix] = res;
+        c_lo_total += c_lo;
+        c_hi_total += c_hi;
+    }
+    {
+        const unsigned long long gm = __ballot(rep && to_generic);
+        if (gm) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(q.gen_count, (unsigned)__popcll(gm));
+            base = __shfl(base, 0, 64);
+            const unsigned slot = base + (unsigned)__popcll(gm & ((1ull << lane) - 1ull));
+            if (rep && to_generic && slot < q.gen_capacity) q.gen_list[slot] = (unsigned)pix;
+        }
+        const unsigned long long em = __ballot(rep && to_exact);
+        if (em) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(q.fb_count, (unsigned)__popcll(em));
+            base = __shfl(base, 0, 64);
+            const unsigned slot = base + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
+            if (rep && to_exact && slot < q.fb_capacity) q.fb_list[slot] = (unsigned)pix;
+        }
+    }
+
+    __shared__ int s_lo[4], s_hi[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c_lo_total += __shfl_xor(c_lo_total, o, 64);
+        c_hi_total += __shfl_xor(c_hi_total, o, 64);
+    }
+    if (lane == 0) { s_lo[threadIdx.x >> 6] = c_lo_total; s_hi[threadIdx.x >> 6] = c_hi_total; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t_lo = 0, t_hi = 0;
+        for (int w = 0; w < L::BLOCK / 64; w++) { t_lo += s_lo[w]; t_hi += s_hi[w]; }
+        unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+        if (t_lo) atomicAdd(slot + 0, (unsigned long long)t_lo);
+        if (t_hi) atomicAdd(slot + 1, (unsigned long long)t_hi);
+    }
+}
+
+// launches the kernel of frame-count class `ntop` if this translation unit instantiates it
+template <int LPP, int... NTOPS>
+static bool launch_mlz_classes(int ntop, bool winsor, const StackArgs &args, const FastArgs &f, hipStream_t stream,
+                               std::integer_sequence<int, NTOPS...>)
+{
+    bool done = false;
+    auto one = [&](auto C) {
+        constexpr int NTOP = decltype(C)::value;
+        if (done || ntop != NTOP) return;
+        using L = MlzLayout<LPP, false, NTOP>;
+        const unsigned blocks = (unsigned)((args.npix + L::PW - 1) / L::PW);
+        if (winsor) hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, true, NTOP>), dim3(blocks), dim3(L::BLOCK), 0, stream, args, f);
+        else        hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, false, NTOP>), dim3(blocks), dim3(L::BLOCK), 0, stream, args, f);
+        done = true;
+    };
+    (one(std::integral_constant<int, NTOPS>{}), ...);
+    return done;
+}
+
+}  // namespace nl

@@ -162,9 +162,9 @@ def test_multi_lane_sigma_129_to_512_frames(nl, oracle, n, clean):
 
 
 @pytest.mark.parametrize("mode", [2, 3])
-@pytest.mark.parametrize("n", [249, 252, 256, 505, 509, 512])
+@pytest.mark.parametrize("n", [129, 144, 145, 200, 249, 252, 256, 257, 300, 384, 385, 470, 505, 509, 512])
 @pytest.mark.parametrize("case", ["clean", "nan", "ties", "heavy", "tight"])
-def test_lds_column_kernels_249_256_and_505_512_frames(nl, oracle, mode, n, case):
+def test_lds_column_kernels_129_to_512_frames(nl, oracle, mode, n, case):
     # stack_fast_mlz.hip: clipping / winsorization rounds on LDS columns with walking pointers.
     # "heavy": 6 % hot and 3 % cold outliers -- clips and clamps run to the ends of the columns
     # (hand-over to the generic pass); "tight": kappa 1.2 / 1.0 clips a fifth of the samples;

@@ -73,3 +73,43 @@ def test_zero_one_exhaustive_small_merges(p):
     bits = ((np.arange(1 << ns)[:, None] >> np.arange(ns)[None, :]) & 1).astype(np.float32)
     y = gen.simulate(ops, out, slots, bits)
     assert np.array_equal(y, np.sort(bits, axis=1))
+
+
+def _parse_bitonic(text):
+    nets = {}
+    for m in re.finditer(r"FusedBitonic<(\d+), (\d+)> \{(.*?)\n\};", text, re.S):
+        ns, keep = int(m.group(1)), int(m.group(2))
+        body = m.group(3)
+        count, slots, ces = (int(x) for x in re.search(r"kCount = (\d+), kSlots = (\d+), kComparators = (\d+)", body).groups())
+        ops_txt = re.search(r"kOps\[\d+\] = \{(.*?)\n    \};", body, re.S).group(1)
+        ops = [tuple(int(x) for x in t.split(",")) for t in re.findall(r"\{([\d,]+)\}", ops_txt)]
+        out = [int(x) for x in re.search(r"kOut\[\d+\] = \{([\d,]+)\}", body).group(1).split(",")]
+        assert len(ops) == count and len(out) == ns
+        nets[(ns, keep)] = (ops, out, slots, ces)
+    return nets
+
+
+def test_bitonic_merge_tables_sort_bitonic_columns():
+    # the half-cleaner cascades of the cross-lane merges (fast_ml_common.hpp): inputs are what a
+    # mirror / distance stage leaves in a lane -- ascending then descending, any rotation, reversed
+    gen = _gen()
+    nets = _parse_bitonic(open(gen.OUT).read())
+    assert set(nets) == set(gen.BITONIC)
+    rng = np.random.default_rng(11)
+    for (ns, keep), (ops, out, slots, ces) in nets.items():
+        assert len(ops) < 2 * ces and max(out) < slots
+        rows = []
+        for r in range(600):
+            vals = rng.standard_normal(ns) * 40 + 900 if r % 2 else rng.integers(0, 4, ns).astype(np.float64)
+            if r % 5 == 0:
+                vals[:7] = np.inf
+            cut = int(rng.integers(0, ns + 1))
+            seq = np.concatenate([np.sort(vals[:cut]), np.sort(vals[cut:])[::-1]])
+            seq = np.roll(seq, int(rng.integers(0, ns))) if r % 3 == 0 else (seq[::-1] if r % 3 == 1 else seq)
+            rows.append(seq)
+        x = np.array(rows, np.float32)
+        y = gen.simulate(ops, out, slots, x)
+        ref = np.sort(x, axis=1)
+        k = keep if keep else ns // 2
+        assert np.array_equal(y[:, :k], ref[:, :k]) and np.array_equal(y[:, ns - k:], ref[:, ns - k:]), (ns, keep)
+        assert np.array_equal(np.sort(y, axis=1), ref), (ns, keep)

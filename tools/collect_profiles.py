@@ -1,25 +1,22 @@
 #!/usr/bin/env python3
-"""Copy the summaries tools/gpu_profile.sh left in gpurun_out/ into profiles/ (tracked) and
-rebuild profiles/r01_traffic.json; prints one line per workload.
-usage: tools/collect_profiles.py tag [tag ...]"""
+"""Copy the summaries tools/gpu_profile.sh left in gpurun_out/ into profiles/ (tracked) under the
+round prefix and rebuild profiles/<round>_traffic.json; prints one line per workload.
+usage: tools/collect_profiles.py <round, e.g. r02> tag [tag ...]"""
 import glob
 import json
 import os
 import shutil
 import sys
 
-tags = sys.argv[1:]
+rnd = sys.argv[1]
+tags = sys.argv[2:]
 entries = []
-for f in glob.glob("profiles/r01_*"):
-    if "first_exact" in f or "ingest" in f:
-        continue
-    os.remove(f)
 for t in tags:
     for suffix in ("kernel_stats.txt", "pmc.txt"):
         txt = open("gpurun_out/%s_%s" % (t, suffix)).read().replace("/tmp/code/mlnoga__nightlight/repo/", "")
-        open("profiles/r01_%s_%s" % (t, suffix), "w").write(txt)
+        open("profiles/%s_%s_%s" % (rnd, t, suffix), "w").write(txt)
     line = [l for l in open("gpurun_out/%s_bench.json" % t) if l.startswith("{")][-1]
-    open("profiles/r01_%s_bench.json" % t, "w").write(line)
+    open("profiles/%s_%s_bench.json" % (rnd, t), "w").write(line)
     e = json.loads(open("gpurun_out/%s_traffic.json" % t).read())
     entries.append(e)
     b = json.loads(line)
@@ -30,12 +27,12 @@ for t in tags:
     print("%-14s pass %8.3f ms  kernel %-46s %8.3f ms (rocprof avg %8.1f us) frac %.3f pass_frac %.3f  traffic/alg %.4f redo %d"
           % (t, b["ms_per_step"], r["kernel"], r["kernel_ms"], avg, r["frac"], r["pass_frac"], ratio,
              r["pixels_redone_by_exact_kernel"]))
-doc = {"_comment": "HBM traffic per launch of the dominant kernel from rocprofv3 PMC passes (profiles/r01_<tag>_pmc.txt): "
+doc = {"_comment": "HBM traffic per launch of the dominant kernel from rocprofv3 PMC passes (profiles/%s_<tag>_pmc.txt)" % rnd + ": "
                    "FETCH_SIZE and WRITE_SIZE in KiB, each collected in its own --pmc run with --kernel-trace only "
                    "(tools/gpu_profile.sh). gfx950 correction per MI355X_MICROARCH.md (HBM section): FETCH_SIZE reports "
                    "half of the bytes of a coalesced streaming read, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE "
                    "is taken as is.",
        "entries": entries}
-json.dump(doc, open("profiles/r01_traffic.json", "w"), indent=1)
+json.dump(doc, open("profiles/%s_traffic.json" % rnd, "w"), indent=1)
 if os.path.exists("gpurun_out/bench_default.json"):
-    shutil.copy("gpurun_out/bench_default.json", "profiles/r01_bench_default_with_cpu_baseline.json")
+    shutil.copy("gpurun_out/bench_default.json", "profiles/%s_bench_default_with_cpu_baseline.json" % rnd)

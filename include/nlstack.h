@@ -168,6 +168,10 @@ int nl_stack_copy_counters_async(nl_stack_t *h, void *device_dst);
 int nl_stack_set_exact(nl_stack_t *h, int on);
 /* Pixels of the last pass that were re-done by the exact kernel. */
 int64_t nl_stack_last_fallback_pixels(nl_stack_t *h);
+/* Linear-fit cascade of the last pass (stack_linfit.hip; StackLinearFit stack.go:834-918 has no
+ * counterpart, diagnostics only): counts[s] = pixels stage s handed to stage s+1 (4 stages).
+ * Writes min(n, 4) values; returns how many, 0 when the last pass ran no cascade. */
+int nl_stack_linfit_stage_counts(nl_stack_t *h, unsigned *counts, int n);
 /* Name of the dominant kernel launched by the last pass (for profiles). */
 const char *nl_stack_last_kernel_name(nl_stack_t *h);
 

@@ -34,7 +34,7 @@ EXPORTS = [
     "nl_stack_upload_frame", "nl_stack_upload_tile", "nl_stack_upload_frame_async", "nl_stack_upload_wait", "nl_stack_frames_device_ptr",
     "nl_stack_attach_device_frames", "nl_stack_fill_synthetic", "nl_stack_download_tile", "nl_stack_download_rows",
     "nl_stack_set_active_frames", "nl_stack_set_weights", "nl_weights_from_scalars",
-    "nl_stack_run", "nl_stack_run_async", "nl_stack_finish", "nl_stack_result_device_ptr",
+    "nl_stack_linfit_stage_counts", "nl_stack_run", "nl_stack_run_async", "nl_stack_finish", "nl_stack_result_device_ptr",
     "nl_stack_last_mode", "nl_stack_last_kernel_ms", "nl_stack_last_dominant_kernel_ms",
     "nl_stack_last_kernel_name", "nl_stack_pass_times", "nl_stack_stream", "nl_stack_counters_device_ptr", "nl_stack_copy_counters_async",
     "nl_group_tile_rows", "nl_group_create", "nl_group_destroy", "nl_group_size", "nl_group_tile",
@@ -140,6 +140,8 @@ def load():
     L.nl_group_accumulate_finalize.argtypes = [vp, C.c_float, _f32p]
     L.nl_stack_last_fallback_pixels.argtypes = [vp]
     L.nl_stack_last_fallback_pixels.restype = C.c_int64
+    L.nl_stack_linfit_stage_counts.argtypes = [vp, C.POINTER(C.c_uint), C.c_int]
+    L.nl_stack_linfit_stage_counts.restype = C.c_int
     L.nl_stack_find_sigmas.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, REDUCE_FN,
                                        vp, _f32p, _i64p, _i64p, _f32p, _f32p, _intp]
     L.nl_stack_accumulate.argtypes = [vp, C.c_float, C.c_int]

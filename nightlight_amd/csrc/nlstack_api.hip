@@ -798,6 +798,18 @@ int64_t nl_stack_last_fallback_pixels(nl_stack_t *h)
     return (int64_t)c;
 }
 
+int nl_stack_linfit_stage_counts(nl_stack_t *h, unsigned *counts, int n)
+{
+    if (!h || !counts || n <= 0 || !h->d_lf_count || h->last_mode != NL_ST_LINEAR_FIT || !h->last_used_fast) return 0;
+    if (hipSetDevice(h->device) != hipSuccess) return -1;
+    unsigned c[nl::kLinfitStages] = {};
+    if (hipMemcpyAsync(c, h->d_lf_count, sizeof c, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+    const int m = n < nl::kLinfitStages ? n : nl::kLinfitStages;
+    for (int i = 0; i < m; i++) counts[i] = c[i];
+    return m;
+}
+
 // GPU times of a pass that is `back` passes old (0 = the last one enqueued); -1 where unavailable
 int nl_stack_pass_times(nl_stack_t *h, int back, float *pass_ms, float *dominant_ms)
 {

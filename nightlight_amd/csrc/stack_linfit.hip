@@ -40,6 +40,23 @@ __device__ __forceinline__ void forget_words(unsigned (&w)[NW])
     if constexpr (NW > 3) asm volatile("" : "+v"(w[3]));
 }
 
+// the chunk classes are wave-uniform: a volatile asm in each arm keeps the compiler from
+// if-converting the scalar branches (it would execute both arms and select)
+#define NL_KEEP_BRANCH asm volatile("")
+
+__device__ __forceinline__ float max3_asm(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float min3_asm(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // 1 if x < 0 (sign bit), else 0 -- integer arithmetic on purpose: a compare
 // would produce a lane mask in SGPRs per element
 __device__ __forceinline__ unsigned sign_bit(float x) { return (unsigned)__float_as_int(x) >> 31; }
@@ -116,18 +133,52 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
     bool active = on && n > 0 && !to_exact;
     int iters = 0;
 
+    // Chunks of 8 positions, classified per iteration for the whole wave (scalar masks): in a
+    // chunk where every fitting lane has all 8 samples alive the sums need no liveness
+    // arithmetic (x * 1.0f == x: the same bits) and the index among the survivors is the
+    // chunk's first index plus a constant -- 14 instead of 45 instructions per sample and
+    // iteration; a chunk that is dead in every fitting lane (pads, the ends of the column in
+    // late iterations) is skipped; only mixed chunks -- where the rejects are happening --
+    // run the masked code.  The reference rejects from the ends of the sorted column inwards
+    // (12 + 12 of 128 samples on the bench stack) and, in late iterations, singles in the
+    // middle; 10-11 of 16 chunks are fully alive on average.
+    constexpr int CH = 8, NC = NS / CH;
+    static_assert(NS % CH == 0, "chunks");
     while (__any(active) && (g.max_iters == 0 || iters < g.max_iters)) {
         iters++;
         const float fm = (float)m;
         const int mt = (active && m >= 1) ? m : 1;
         const float xm = p.xstat[2 * mt], xsd = p.xstat[2 * mt + 1];
-        // liveness of position k as 0.0f / 1.0f:  x * lf  is x or +-0, exactly
-#define NL_LF(k) ((float)((live[(k) >> 5] >> ((k) & 31)) & 1u))
+        unsigned aa = 0, ad = 0;                // bit c: chunk c all alive / all dead in every fitting lane
+        static_range<0, NC>([&](auto C) NL_INL {
+            constexpr int c = decltype(C)::value;
+            const unsigned byte = (live[c >> 2] >> (8 * (c & 3))) & 0xffu;
+            aa |= (__ballot(active && byte != 0xffu) == 0ull ? 1u : 0u) << c;
+            ad |= (__ballot(active && byte != 0u) == 0ull ? 1u : 0u) << c;
+        });
+        aa = (unsigned)__builtin_amdgcn_readfirstlane((int)aa);
+        ad = (unsigned)__builtin_amdgcn_readfirstlane((int)ad);
+        // liveness of position k as an all-ones / zero word: x & m is x or +0 -- a dead sample adds
+        // +0 to a sum, as skipping it does (an accumulator that starts at +0 never becomes -0).
+        // (Not x * 0.0f: that is NaN for a dead sample whose square overflowed, and the compiler
+        // pairs such multiplies into v_pk_mul_f32, which wants a second, pair-aligned copy of the column.)
+#define NL_M(k) ((int)(live[(k) >> 5] << (31 - ((k) & 31))) >> 31)
+#define NL_AND(x, m) __int_as_float(__float_as_int(x) & (m))
         // ---- MeanStdDev(ys), stats.go:246-261, sequential in sorted order ----
         float s = 0.0f;
-        static_chunks<0, NS, 16>([&](auto K) NL_INL {
-            constexpr int k = decltype(K)::value;
-            s = __fadd_rn(s, __fmul_rn(v[k], NL_LF(k)));
+        static_range<0, NC>([&](auto C) NL_INL {
+            constexpr int c = decltype(C)::value;
+            if ((ad >> c) & 1u) {
+            } else if ((aa >> c) & 1u) {
+                NL_KEEP_BRANCH;
+                static_range<c * CH, c * CH + CH>([&](auto K) NL_INL { s = __fadd_rn(s, v[decltype(K)::value]); });
+            } else {
+                NL_KEEP_BRANCH;
+                static_range<c * CH, c * CH + CH>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    s = __fadd_rn(s, NL_AND(v[k], NL_M(k)));
+                });
+            }
         });
         const float ym = s / fm;
         // ---- variance of the ys and the correlation sum (stats.go:573-579; divisor n+1,
@@ -135,16 +186,34 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
         // terms in index order ----
         float vs = 0.0f, corr = 0.0f, fi = 0.0f;
         forget_words<NW>(live);
-        static_chunks<0, NS, 16>([&](auto K) NL_INL {
-            constexpr int k = decltype(K)::value;
-            const float lf = NL_LF(k);
-            const float dy = __fsub_rn(v[k], ym);
-            const float dd = __fmul_rn(dy, dy);
-            vs = __fadd_rn(vs, __fmul_rn(dd, lf));
-            const float dx = __fsub_rn(fi, xm);
-            const float t = __fmul_rn(dx, dy);
-            corr = __fadd_rn(corr, __fmul_rn(t, lf));
-            fi += lf;                                            // index among the survivors
+        static_range<0, NC>([&](auto C) NL_INL {
+            constexpr int c = decltype(C)::value;
+            if ((ad >> c) & 1u) {
+            } else if ((aa >> c) & 1u) {
+                NL_KEEP_BRANCH;
+                // fl(i - xm) is exact (half-integers below 2^23), so (fi - xm) + j is the same float
+                const float dxb = __fsub_rn(fi, xm);
+                static_range<0, CH>([&](auto J) NL_INL {
+                    constexpr int j = decltype(J)::value;
+                    const float dy = __fsub_rn(v[c * CH + j], ym);
+                    vs = __fadd_rn(vs, __fmul_rn(dy, dy));
+                    corr = __fadd_rn(corr, __fmul_rn(__fadd_rn(dxb, (float)j), dy));
+                });
+                fi += (float)CH;
+            } else {
+                NL_KEEP_BRANCH;
+                static_range<c * CH, c * CH + CH>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    const int lm = NL_M(k);
+                    const float dy = __fsub_rn(v[k], ym);
+                    const float dd = __fmul_rn(dy, dy);
+                    vs = __fadd_rn(vs, NL_AND(dd, lm));
+                    const float dx = __fsub_rn(fi, xm);
+                    const float t = __fmul_rn(dx, dy);
+                    corr = __fadd_rn(corr, NL_AND(t, lm));
+                    fi += NL_AND(1.0f, lm);                              // index among the survivors
+                });
+            }
         });
         const float ysd = sqrt_go(vs / fm);
         float den = __fmul_rn(xsd, ysd);
@@ -155,16 +224,46 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
         float icpt = __fsub_rn(ym, __fmul_rn(slope, xm));
         // ---- mean absolute deviation from the fit, stack.go:879-886 ----
         // (a NaN fit -- ystddev 0 -- makes every term NaN in the reference too)
+        // In the all-alive chunks the extremes of the residuals are kept: they decide below
+        // whether any of those samples is rejected (fl(lin - g) == -fl(g - lin), so the one
+        // difference serves both of the reference's tests).  max / min as the instructions, two
+        // residuals each: the compiler re-associates fmaxf / fminf chains into a tree over all
+        // the residuals and spills the column for it.
         float sg = 0.0f;
+        float dmax[NW], dmin[NW];               // per 32 positions
+        static_range<0, NW>([&](auto W) NL_INL { dmax[decltype(W)::value] = -__builtin_inff(); dmin[decltype(W)::value] = __builtin_inff(); });
         fi = 0.0f;
         forget_words<NW>(live);
-        static_chunks<0, NS, 16>([&](auto K) NL_INL {
-            constexpr int k = decltype(K)::value;
-            const float lf = NL_LF(k);
-            const float lin = __fadd_rn(__fmul_rn(fi, slope), icpt);
-            const float diff = __fsub_rn(v[k], lin);
-            sg = __fadd_rn(sg, __fmul_rn(fabsf(diff), lf));
-            fi += lf;
+        static_range<0, NC>([&](auto C) NL_INL {
+            constexpr int c = decltype(C)::value;
+            if ((ad >> c) & 1u) {
+            } else if ((aa >> c) & 1u) {
+                NL_KEEP_BRANCH;
+                float dprev = 0.0f;
+                static_range<0, CH>([&](auto J) NL_INL {
+                    constexpr int j = decltype(J)::value;
+                    const float lin = __fadd_rn(__fmul_rn(__fadd_rn(fi, (float)j), slope), icpt);
+                    const float diff = __fsub_rn(v[c * CH + j], lin);
+                    sg = __fadd_rn(sg, fabsf(diff));
+                    if constexpr ((j & 1) == 0) {
+                        dprev = diff;
+                    } else {
+                        dmax[c >> 2] = max3_asm(dmax[c >> 2], dprev, diff);
+                        dmin[c >> 2] = min3_asm(dmin[c >> 2], dprev, diff);
+                    }
+                });
+                fi += (float)CH;
+            } else {
+                NL_KEEP_BRANCH;
+                static_range<c * CH, c * CH + CH>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    const int lm = NL_M(k);
+                    const float lin = __fadd_rn(__fmul_rn(fi, slope), icpt);
+                    const float diff = __fsub_rn(v[k], lin);
+                    sg = __fadd_rn(sg, NL_AND(fabsf(diff), lm));
+                    fi += NL_AND(1.0f, lm);
+                });
+            }
         });
         sg = sg / fm;
         // ---- reject, stack.go:890-904 ----
@@ -174,27 +273,49 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
         float lb = __fmul_rn(p.sig_lo, sg), hb = __fmul_rn(p.sig_hi, sg);
         const bool bad = !(slope == slope) || !(icpt == icpt) || !(lb == lb) || !(hb == hb);
         if (bad) { slope = 0.0f; icpt = 0.0f; lb = __builtin_inff(); hb = __builtin_inff(); }
+        // a sample of an all-alive chunk is rejected in some lane (lin - g > lb <=> diff < -lb,
+        // g - lin > hb <=> diff > hb; a NaN fit rejects nothing): then those chunks take the masked
+        // pass as well -- their bits are all set, and it finds nothing in the other lanes.  Decided per
+        // 32 positions: it happens in two of three iterations of a wave (some lane's clipped end
+        // reaches the next chunk, or a late fit rejects a single in the middle).
+        unsigned holed = 0;
+        static_range<0, NW>([&](auto W) NL_INL {
+            constexpr int w = decltype(W)::value;
+            holed |= (__any(active && !bad && (dmin[w] < -lb || dmax[w] > hb)) ? 1u : 0u) << w;
+        });
+        holed = (unsigned)__builtin_amdgcn_readfirstlane((int)holed);
         unsigned lo_n = 0, hi_n = 0;
         unsigned nlive[NW];
         static_range<0, NW>([&](auto W) NL_INL { nlive[decltype(W)::value] = live[decltype(W)::value]; });
         fi = 0.0f;
         forget_words<NW>(live);
         slope = opaque_f(slope);
-        static_chunks<0, NS, 16>([&](auto K) NL_INL {
-            constexpr int k = decltype(K)::value;
-            const unsigned lbit = (live[k >> 5] >> (k & 31)) & 1u;
-            const float g = v[k];
-            const float lin = __fadd_rn(__fmul_rn(fi, slope), icpt);
-            const unsigned low = sign_bit(__fsub_rn(lb, __fsub_rn(lin, g))) & lbit;
-            const unsigned high = sign_bit(__fsub_rn(hb, __fsub_rn(g, lin))) & lbit & ~low;
-            // (opaque: integer sums may be re-associated, and the compiler would
-            // first compute the bits of all samples and only then add them up)
-            lo_n = opaque_u(lo_n + low);
-            hi_n = opaque_u(hi_n + high);
-            nlive[k >> 5] = opaque_u(nlive[k >> 5] & ~((low | high) << (k & 31)));
-            fi += (float)lbit;
+        static_range<0, NC>([&](auto C) NL_INL {
+            constexpr int c = decltype(C)::value;
+            if ((ad >> c) & 1u) {
+            } else if (((aa >> c) & 1u) && !((holed >> (c >> 2)) & 1u)) {
+                NL_KEEP_BRANCH;
+                fi += (float)CH;
+            } else {
+                NL_KEEP_BRANCH;
+                static_range<c * CH, c * CH + CH>([&](auto K) NL_INL {
+                    constexpr int k = decltype(K)::value;
+                    const unsigned lbit = (live[k >> 5] >> (k & 31)) & 1u;
+                    const float g = v[k];
+                    const float lin = __fadd_rn(__fmul_rn(fi, slope), icpt);
+                    const unsigned low = sign_bit(__fsub_rn(lb, __fsub_rn(lin, g))) & lbit;
+                    const unsigned high = sign_bit(__fsub_rn(hb, __fsub_rn(g, lin))) & lbit & ~low;
+                    // (opaque: integer sums may be re-associated, and the compiler would
+                    // first compute the bits of all samples and only then add them up)
+                    lo_n = opaque_u(lo_n + low);
+                    hi_n = opaque_u(hi_n + high);
+                    nlive[k >> 5] = opaque_u(nlive[k >> 5] & ~((low | high) << (k & 31)));
+                    fi += (float)lbit;
+                });
+            }
         });
-#undef NL_LF
+#undef NL_M
+#undef NL_AND
         if (active) {
             p_lo += (int)lo_n;
             p_hi += (int)hi_n;

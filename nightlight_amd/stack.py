@@ -145,6 +145,13 @@ class StackHandle:
         return int(self._lib.nl_stack_last_fallback_pixels(self._h))
 
     @property
+    def linfit_stage_counts(self):
+        """list lengths of the last linear-fit cascade (see include/nlstack.h); [] if none ran"""
+        buf = (C.c_uint * 4)()
+        k = int(self._lib.nl_stack_linfit_stage_counts(self._h, buf, 4))
+        return [int(buf[i]) for i in range(max(k, 0))]
+
+    @property
     def last_mode(self):
         return self._lib.nl_stack_last_mode(self._h)
 

@@ -222,6 +222,30 @@ def test_register_resident_linear_fit_is_bit_exact(nl, oracle, n):
         assert gc == wc, "linear fit n=%d clip counters %r vs oracle %r" % (n, gc, wc)
 
 
+@pytest.mark.parametrize("n", [24, 57, 96, 120, 127, 128])
+@pytest.mark.parametrize("case", ["clean", "nan", "holes", "hot", "tight", "ties"])
+def test_linear_fit_chunk_classes_are_bit_exact(nl, oracle, n, case):
+    # stack_linfit.hip classifies chunks of 8 column positions per wave and iteration: all alive in
+    # every fitting lane (no liveness arithmetic; rejects there are detected from the extremes of
+    # the residuals and then the masked pass runs), all dead (skipped), mixed (masked).  Every route
+    # must be bit-exact: whole waves without missing samples (clean: all three classes over the
+    # iterations), missing samples at the top of the column (nan), ragged columns (holes: 30 % NaN),
+    # many rejections (hot: 30 % outliers; tight: kappa 0.8 cuts into the middle), ties.
+    width, height = 96, 24
+    kw = dict(nan_frac=0.0, nan_border=False, all_nan_patch=False)
+    if case == "nan":
+        kw = dict(nan_frac=0.03)
+    elif case == "holes":
+        kw = dict(nan_frac=0.3)
+    elif case == "hot":
+        kw.update(hot=0.2, cold=0.1)
+    frames = make_frames(n, width, height, seed=7100 + n, ties=(case == "ties"), **kw)
+    sl, sh = (0.8, 0.8) if case == "tight" else (3.0, 2.5)
+    got, gc, want, wc = run_both(nl, oracle, 5, frames, width, height, None, sl, sh, exact=False)
+    assert same_values(got, want), "linear fit n=%d %s: %s" % (n, case, describe_mismatch(got, want))
+    assert gc == wc, "linear fit n=%d %s clip counters %r vs oracle %r" % (n, case, gc, wc)
+
+
 def test_fast_sigma_clean_frames_no_nan(nl, oracle):
     # no missing samples at all: every wave stays in the zonal passes
     width, height, n = 256, 64, 128

@@ -168,6 +168,9 @@ int nl_stack_copy_counters_async(nl_stack_t *h, void *device_dst);
 int nl_stack_set_exact(nl_stack_t *h, int on);
 /* Pixels of the last pass that were re-done by the exact kernel. */
 int64_t nl_stack_last_fallback_pixels(nl_stack_t *h);
+/* Pixels of the last pass that the dominant kernel handed to the generic pass (all positions
+ * masked by rank: pixels that miss many samples or clip more than the clip zones hold). */
+int64_t nl_stack_last_generic_pixels(nl_stack_t *h);
 /* Linear-fit cascade of the last pass (stack_linfit.hip; StackLinearFit stack.go:834-918 has no
  * counterpart, diagnostics only): counts[s] = pixels stage s handed to stage s+1 (4 stages).
  * Writes min(n, 4) values; returns how many, 0 when the last pass ran no cascade. */

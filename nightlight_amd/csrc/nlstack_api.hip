@@ -566,6 +566,9 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         f.fb_list = h->d_fb_list;
         f.fb_count = h->d_fb_count;
         f.fb_capacity = (unsigned)h->npix;
+        f.gen_list = h->d_gen_list;                 // 128 frames: pixels with too few samples for the selection kernel
+        f.gen_count = h->d_fb_count + 1;
+        f.gen_capacity = (unsigned)h->npix;
         if (a.n_frames <= 128) NL_HIP(nl::launch_stack_mad_fast(a, f, h->stream, &h->last_kernel));
         else                   NL_HIP(nl::launch_stack_mad_ml(a, f, h->stream, &h->last_kernel));
         NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
@@ -794,6 +797,16 @@ int64_t nl_stack_last_fallback_pixels(nl_stack_t *h)
     if (hipSetDevice(h->device) != hipSuccess) return -1;
     unsigned c = 0;
     if (hipMemcpyAsync(&c, h->d_fb_count, sizeof c, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+    return (int64_t)c;
+}
+
+int64_t nl_stack_last_generic_pixels(nl_stack_t *h)
+{
+    if (!h || !h->last_used_fast || !h->d_fb_count || !h->d_gen_list) return 0;
+    if (hipSetDevice(h->device) != hipSuccess) return -1;
+    unsigned c = 0;
+    if (hipMemcpyAsync(&c, h->d_fb_count + 1, sizeof c, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
     return (int64_t)c;
 }

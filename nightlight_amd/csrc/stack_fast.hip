@@ -125,9 +125,16 @@ template <int NS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS > 96 ? 3 : 1, 8)))
 void stack_mad_fast_kernel(StackArgs p, FastArgs q)
 {
-    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool on = pix < p.npix;
+    // q.in_list: the pixels stack_mad_bitonic_kernel handed over (the list's length is only known on
+    // the device: fixed grid, grid-stride loop); otherwise the grid covers the tile
+    const int64_t limit = q.in_list ? (int64_t)min(*q.in_count, q.in_capacity) : p.npix;
     const int lane = threadIdx.x & 63;
+    int c_lo_sum = 0, c_hi_sum = 0;
+  for (int64_t item0 = (int64_t)blockIdx.x * blockDim.x; item0 < limit; item0 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t item = item0 + threadIdx.x;
+    const bool on = item < limit;
+    int64_t pix = item;
+    if (q.in_list) pix = on ? (int64_t)q.in_list[item] : 0;
     const unsigned boff = (unsigned)(on ? pix : 0) * 4u;
     int N = p.n_frames;
     asm volatile("" : "+s"(N));
@@ -194,6 +201,8 @@ void stack_mad_fast_kernel(StackArgs p, FastArgs q)
     const bool to_exact = on && degenerate;
     if (on && !to_exact) p.out[pix] = res;
     if (!on || to_exact || n == 0) { c_lo = 0; c_hi = 0; }
+    c_lo_sum += c_lo;
+    c_hi_sum += c_hi;
     const unsigned long long em = __ballot(to_exact);
     if (em) {
         unsigned base = 0;
@@ -201,6 +210,122 @@ void stack_mad_fast_kernel(StackArgs p, FastArgs q)
         base = __shfl(base, 0, 64);
         const unsigned slot = base + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
         if (to_exact && slot < q.fb_capacity) q.fb_list[slot] = (unsigned)pix;
+    }
+  }
+    int c_lo = c_lo_sum, c_hi = c_hi_sum;
+    __shared__ int s_lo[4], s_hi[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c_lo += __shfl_xor(c_lo, o, 64);
+        c_hi += __shfl_xor(c_hi, o, 64);
+    }
+    if (lane == 0) { s_lo[threadIdx.x >> 6] = c_lo; s_hi[threadIdx.x >> 6] = c_hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t_l = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3];
+        const int t_h = s_hi[0] + s_hi[1] + s_hi[2] + s_hi[3];
+        unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+        if (t_l) atomicAdd(slot + 0, (unsigned long long)t_l);
+        if (t_h) atomicAdd(slot + 1, (unsigned long long)t_h);
+    }
+}
+
+// 128 frames: no second sort and no second read.  The deviations |x - median| of a SORTED column
+// fall to the median and rise again -- a bitonic sequence (rounding is monotone; pads stay +Inf at
+// the top) -- so the half-cleaner cascade of a bitonic merge would sort them, and only the ranks
+// the MAD can occupy are wanted (56..71 for n >= 114 samples): L_i = min(d_i, d_i+64) are the 64
+// smallest deviations, U_i = max(d_i, d_i+64) the 64 largest; the maxima of the L_i over
+// i = j mod 8 are, once sorted, ranks 56..63, the minima of the U_i ranks 64..71.  About 370
+// instructions on the fly instead of a 2184-instruction sort of a second column, and the samples
+// stay in their registers for the clip and the mean (summed in sorted order: the reference sums
+// in the order its quickselects left -- summation-order rounding either way).  Pixels with fewer
+// than 114 samples go to q.gen_list, which stack_mad_fast_kernel<128> finishes.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8)))
+void stack_mad_bitonic_kernel(StackArgs p, FastArgs q)
+{
+    constexpr int NS = 128;
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = pix < p.npix;
+    const int lane = threadIdx.x & 63;
+    const unsigned boff = (unsigned)(on ? pix : 0) * 4u;
+    int N = p.n_frames;
+    asm volatile("" : "+s"(N));
+    float v[NS];
+    const int n = gather_sorted<NS, 16, FullSortT<false>>(p.frames, p.stride, N, boff, v);
+    const bool narrow = on && n > 0 && n < 114;
+    const int kk = min(max(n >> 1, 57), 64);                 // qsort.go:70: k = (n>>1)+1, 1-based (clamped for lanes that leave)
+    float upper, lower;
+    pick_pair<56, 65>(v, kk, lower, upper);
+    const float median = (n & 1) ? upper : 0.5f * (lower + upper);
+    const bool degenerate = n > 0 && !(__builtin_fabsf(median) < __builtin_inff());
+    const float msafe = degenerate ? 0.0f : median;
+    float win[16];
+    static_range<0, 8>([&](auto J) NL_INL {
+        constexpr int j = decltype(J)::value;
+        float w = -__builtin_inff(), u = __builtin_inff();
+        static_range<0, 8>([&](auto T) NL_INL {
+            constexpr int i = j + 8 * decltype(T)::value;
+            const float dl = __builtin_fabsf(v[i] - msafe), dr = __builtin_fabsf(v[i + 64] - msafe);   // stack.go:566-571
+            w = fmaxf(w, fminf(dl, dr));
+            u = fminf(u, fmaxf(dl, dr));
+        });
+        win[j] = w;
+        win[8 + j] = u;
+    });
+    // two bitonic runs of 8: distances 4, 2, 1
+    static_range<0, 3>([&](auto S) NL_INL {
+        constexpr int dist = 4 >> decltype(S)::value;
+        static_range<0, 16>([&](auto I) NL_INL {
+            constexpr int i = decltype(I)::value;
+            if constexpr ((i & dist) == 0) {
+                const float a = win[i], b = win[i + dist];
+                win[i] = fminf(a, b);
+                win[i + dist] = fmaxf(a, b);
+            }
+        });
+    });
+    float dupper, dlower;
+    pick_pair<0, 16>(win, kk - 56, dlower, dupper);          // ranks kk-1, kk of the deviations
+    const float mad = (n & 1) ? dupper : 0.5f * (dlower + dupper);
+    const float sd = mad * 1.4826f;                          // stack.go:574
+    const float t_lo = p.sig_lo * sd, t_hi = p.sig_hi * sd;
+    const float lo = median - t_lo, hi = median + t_hi;
+    float f_lo = 0.0f, f_hi = 0.0f, f_kept = 0.0f, sum = 0.0f;
+    int nn = n;
+    static_chunks<0, NS, 4>([&](auto K) NL_INL {
+        constexpr int k = decltype(K)::value;
+        const float x = v[k];
+        if constexpr ((k & 7) == 0) nn = opaque(nn);
+        const bool present = k < nn;                         // pads (+Inf) sort last
+        const bool below = present && x < lo;                // stack.go:583-592: low first
+        const bool above = present && !below && x > hi;
+        const bool keep = present && !below && !above;
+        f_lo += below ? 1.0f : 0.0f;
+        f_hi += above ? 1.0f : 0.0f;
+        f_kept += keep ? 1.0f : 0.0f;
+        sum += keep ? x : 0.0f;
+        asm volatile("" : "+v"(f_lo), "+v"(f_hi), "+v"(f_kept), "+v"(sum));
+    });
+    int c_lo = (int)f_lo, c_hi = (int)f_hi;
+    float res = sum / f_kept;                                // no survivor: 0/0 = NaN, as the reference
+    if (n == 0) res = p.ref_loc;
+    const bool to_exact = on && degenerate && !narrow;
+    if (on && !to_exact && !narrow) p.out[pix] = res;
+    if (!on || to_exact || narrow || n == 0) { c_lo = 0; c_hi = 0; }
+    const unsigned long long em = __ballot(to_exact), gm = __ballot(narrow);
+    if (em) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(q.fb_count, (unsigned)__popcll(em));
+        base = __shfl(base, 0, 64);
+        const unsigned slot = base + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
+        if (to_exact && slot < q.fb_capacity) q.fb_list[slot] = (unsigned)pix;
+    }
+    if (gm) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(q.gen_count, (unsigned)__popcll(gm));
+        base = __shfl(base, 0, 64);
+        const unsigned slot = base + (unsigned)__popcll(gm & ((1ull << lane) - 1ull));
+        if (narrow && slot < q.gen_capacity) q.gen_list[slot] = (unsigned)pix;
     }
     __shared__ int s_lo[4], s_hi[4];
 #pragma unroll
@@ -742,7 +867,21 @@ hipError_t launch_stack_mad_fast(const StackArgs &args, const FastArgs &fargs, h
     else if (n <= 80)  launch_mad<80>(args, fargs, blocks, stream, name);
     else if (n <= 96)  launch_mad<96>(args, fargs, blocks, stream, name);
     else if (n <= 112) launch_mad<112>(args, fargs, blocks, stream, name);
-    else               launch_mad<128>(args, fargs, blocks, stream, name);
+    else if (n < 114 || !fargs.gen_list) launch_mad<128>(args, fargs, blocks, stream, name);
+    else {
+        *name = "stack_mad_bitonic_kernel";
+        FastArgs f = fargs;
+        f.in_list = nullptr;
+        f.in_count = nullptr;
+        f.in_capacity = 0;
+        hipLaunchKernelGGL(stack_mad_bitonic_kernel, dim3(blocks), dim3(256), 0, stream, args, f);
+        // the pixels with fewer than 114 samples (aligned frames' borders): two sorts, second read
+        f.in_list = fargs.gen_list;
+        f.in_count = fargs.gen_count;
+        f.in_capacity = fargs.gen_capacity;
+        const unsigned gblocks = blocks < kGenericGrid ? blocks : kGenericGrid;
+        hipLaunchKernelGGL(stack_mad_fast_kernel<128>, dim3(gblocks), dim3(256), 0, stream, args, f);
+    }
     return hipGetLastError();
 }
 
@@ -786,8 +925,15 @@ static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned t
         f.in_count = fargs.gen_count;
         f.in_capacity = fargs.gen_capacity;
         const unsigned gblocks = tile_blocks < kGenericGrid ? tile_blocks : kGenericGrid;
-        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false, WINSOR, false>), dim3(gblocks), dim3(256), 0,
-                           stream, args, f);
+        if constexpr (WINSOR && NS > 64) {
+            // whole columns + prefix sums in LDS (stack_fast_mlg.hip): a winsorization round is a few
+            // LDS reads instead of a pass over 128 masked registers
+            const unsigned lblocks = 4 * tile_blocks < 4 * kGenericGrid ? 4 * tile_blocks : 4 * kGenericGrid;
+            (void)launch_stack_sigma_mlg(args, f, lblocks, stream, true);
+        } else {
+            hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false, WINSOR, false>), dim3(gblocks), dim3(256), 0,
+                               stream, args, f);
+        }
     } else {
         // small stacks: generic passes are cheap, run them over the whole tile
         *name = sigma_kernel_name<NS, false, WINSOR, false>();

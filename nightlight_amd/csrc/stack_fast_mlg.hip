@@ -1,5 +1,6 @@
 // stack_fast_mlg.hip -- the GENERIC pass of the multi-lane sigma / winsorized sigma kernels
-// (129..512 frames): pixels a zonal kernel (stack_fast_ml.hip, stack_fast_mlz.hip) handed over
+// (129..512 frames; 65..128 frames for winsorized clipping): pixels a zonal kernel (stack_fast.hip,
+// stack_fast_ml.hip, stack_fast_mlz.hip) handed over
 // because they miss too many samples (the NaN borders of aligned frames) or clip / clamp more
 // samples than its zones hold.
 //
@@ -167,7 +168,9 @@ void stack_sigma_mlg_kernel(StackArgs p, FastArgs q)
         if (q.in_list) pix = on ? (int64_t)q.in_list[item] : 0;
 
         float v[NS];
-        const int n = ml_gather_sorted<LPP, NS, false>(p.frames, p.stride, N, on, pix, role, v);
+        int n;
+        if constexpr (LPP == 1) n = gather_sorted<NS, NS>(p.frames, p.stride, N, (unsigned)(on ? pix : 0) * 4u, v);
+        else                    n = ml_gather_sorted<LPP, NS, false>(p.frames, p.stride, N, on, pix, role, v);
 
         // ---- the whole column to LDS: lane r holds ranks [r NS, r NS + NS) ----
         {
@@ -192,7 +195,7 @@ void stack_sigma_mlg_kernel(StackArgs p, FastArgs q)
             const float t1 = (d0 + d1) + (d2 + d3), t2 = (q0 + q1) + (q2 + q3);
             // totals of the lanes below this one (missing samples = +Inf only reach entries above n, never read)
             float o1 = 0.0f, o2 = 0.0f;
-            {
+            if constexpr (LPP > 1) {
                 const float a1 = dpp_f<kSwap1>(t1), a2 = dpp_f<kSwap1>(t2);       // partner lane ^ 1
                 if constexpr (LPP == 2) {
                     o1 = (role & 1) ? a1 : 0.0f;
@@ -375,11 +378,18 @@ void stack_sigma_mlg_kernel(StackArgs p, FastArgs q)
     }
 }
 
-// generic pass over fargs.in_list (the hand-over list of a zonal kernel), 129..512 frames
+// generic pass over fargs.in_list (the hand-over list of a zonal kernel): 2 or 4 lanes per pixel for
+// 129..512 frames; one lane per pixel (64 pixels per wave, the same 48 KiB) for the winsorized
+// one-lane kernels of stack_fast.hip, whose register version of this pass runs 28 lock-step
+// winsorization rounds over all 128 masked positions -- 1.0 ms for the 57 k border pixels of a
+// 128 x 4096^2 stack, less than one wave per SIMD, pure latency
 hipError_t launch_stack_sigma_mlg(const StackArgs &args, const FastArgs &fargs, unsigned grid, hipStream_t stream,
                                   bool winsor)
 {
-    if (args.n_frames <= 2 * kMlNS) {
+    if (args.n_frames <= kMlNS) {
+        if (winsor) hipLaunchKernelGGL((stack_sigma_mlg_kernel<1, true>), dim3(grid), dim3(64), 0, stream, args, fargs);
+        else        hipLaunchKernelGGL((stack_sigma_mlg_kernel<1, false>), dim3(grid), dim3(64), 0, stream, args, fargs);
+    } else if (args.n_frames <= 2 * kMlNS) {
         if (winsor) hipLaunchKernelGGL((stack_sigma_mlg_kernel<2, true>), dim3(grid), dim3(64), 0, stream, args, fargs);
         else        hipLaunchKernelGGL((stack_sigma_mlg_kernel<2, false>), dim3(grid), dim3(64), 0, stream, args, fargs);
     } else {

@@ -15,6 +15,8 @@
 // One pixel per lane, samples in VGPRs, no LDS, no hand-over lists (a pixel
 // with a +-Inf sample is replayed by the LDS kernel: its pads are +Inf too).
 // MeanStdDev of xs = 0..m-1 depends on m only and comes from the host table.
+#include <cstdio>
+#include <cstdlib>
 #include "fast_ml_common.hpp"
 
 namespace nl {
@@ -71,6 +73,9 @@ struct LinfitStage {
     int max_iters;            // fit iterations this stage may run per pixel (0: unlimited)
 };
 
+#ifndef NL_LF_CHUNK
+#define NL_LF_CHUNK 8
+#endif
 template <int NS, bool CONT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS > 96 ? 3 : 1, 8)))
 void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
@@ -142,7 +147,7 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
     // run the masked code.  The reference rejects from the ends of the sorted column inwards
     // (12 + 12 of 128 samples on the bench stack) and, in late iterations, singles in the
     // middle; 10-11 of 16 chunks are fully alive on average.
-    constexpr int CH = 8, NC = NS / CH;
+    constexpr int CH = NL_LF_CHUNK, NC = NS / CH, CPW = 32 / CH;     // chunks per liveness word
     static_assert(NS % CH == 0, "chunks");
     while (__any(active) && (g.max_iters == 0 || iters < g.max_iters)) {
         iters++;
@@ -152,8 +157,9 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
         unsigned aa = 0, ad = 0;                // bit c: chunk c all alive / all dead in every fitting lane
         static_range<0, NC>([&](auto C) NL_INL {
             constexpr int c = decltype(C)::value;
-            const unsigned byte = (live[c >> 2] >> (8 * (c & 3))) & 0xffu;
-            aa |= (__ballot(active && byte != 0xffu) == 0ull ? 1u : 0u) << c;
+            constexpr unsigned full = (1u << CH) - 1u;
+            const unsigned byte = (live[c / CPW] >> (CH * (c % CPW))) & full;
+            aa |= (__ballot(active && byte != full) == 0ull ? 1u : 0u) << c;
             ad |= (__ballot(active && byte != 0u) == 0ull ? 1u : 0u) << c;
         });
         aa = (unsigned)__builtin_amdgcn_readfirstlane((int)aa);
@@ -248,8 +254,8 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
                     if constexpr ((j & 1) == 0) {
                         dprev = diff;
                     } else {
-                        dmax[c >> 2] = max3_asm(dmax[c >> 2], dprev, diff);
-                        dmin[c >> 2] = min3_asm(dmin[c >> 2], dprev, diff);
+                        dmax[c / CPW] = max3_asm(dmax[c / CPW], dprev, diff);
+                        dmin[c / CPW] = min3_asm(dmin[c / CPW], dprev, diff);
                     }
                 });
                 fi += (float)CH;
@@ -293,7 +299,7 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
         static_range<0, NC>([&](auto C) NL_INL {
             constexpr int c = decltype(C)::value;
             if ((ad >> c) & 1u) {
-            } else if (((aa >> c) & 1u) && !((holed >> (c >> 2)) & 1u)) {
+            } else if (((aa >> c) & 1u) && !((holed >> (c / CPW)) & 1u)) {
                 NL_KEEP_BRANCH;
                 fi += (float)CH;
             } else {
@@ -655,6 +661,22 @@ int linfit_fast_supported(int mode, int n_frames, int64_t npix)
     return (mode == NL_ST_LINEAR_FIT && n_frames >= 1 && n_frames <= 128 && npix < kFastMaxPixels) ? 1 : 0;
 }
 
+// fit iterations per cascade stage (the last stage runs to the end); NL_LF_QUOTA="a,b,c" overrides
+// the first three for tuning runs
+static const int *linfit_quota()
+{
+    static int quota[kLinfitStages] = {8, 6, 8, 0};     // measured: 19.7 ms vs 20.2 (6,6,8), 20.4 (10,8,8), 21.1 (5,5,8) on 128 x 4096^2
+    static bool parsed = false;
+    if (!parsed) {
+        parsed = true;
+        if (const char *e = getenv("NL_LF_QUOTA")) {
+            int a = 0, b = 0, c = 0;
+            if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { quota[0] = a; quota[1] = b; quota[2] = c; }
+        }
+    }
+    return quota;
+}
+
 template <int NS>
 static void launch_lf(const StackArgs &args, const FastArgs &f, const LinfitCascade *c, unsigned blocks,
                       hipStream_t stream, hipEvent_t dominant_done)
@@ -668,7 +690,7 @@ static void launch_lf(const StackArgs &args, const FastArgs &f, const LinfitCasc
     // Fit iterations per stage.  The number a pixel needs varies a lot (8 on average, 20-26
     // for the slowest lane of a wave): capping a stage and re-packing the unfinished pixels
     // into full waves halves the lane-iterations, at the price of re-sorting those pixels.
-    static const int quota[kLinfitStages] = {6, 6, 8, 0};
+    const int *quota = linfit_quota();
     for (int s = 0; s < kLinfitStages; s++) {
         g.max_iters = quota[s];
         g.in_list = s ? c->list[(s - 1) & 1] : nullptr;

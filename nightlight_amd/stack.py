@@ -145,6 +145,10 @@ class StackHandle:
         return int(self._lib.nl_stack_last_fallback_pixels(self._h))
 
     @property
+    def last_generic_pixels(self):
+        return int(self._lib.nl_stack_last_generic_pixels(self._h))
+
+    @property
     def linfit_stage_counts(self):
         """list lengths of the last linear-fit cascade (see include/nlstack.h); [] if none ran"""
         buf = (C.c_uint * 4)()

@@ -583,6 +583,29 @@ def test_register_resident_mad_counts_exact_values_close(nl, oracle, n):
         assert close_values(got, want), "mad n=%d: %s" % (n, describe_mismatch(got, want))
 
 
+@pytest.mark.parametrize("n", [114, 115, 121, 127, 128])
+@pytest.mark.parametrize("case", ["clean", "nan", "ties", "hot"])
+def test_mad_selection_kernel_114_to_128_frames(nl, oracle, n, case):
+    # stack_mad_bitonic_kernel: the deviations of a sorted column are bitonic, the MAD is selected from
+    # half-cleaner minima / maxima without a second sort, clip and mean run on the registers; pixels
+    # with fewer than 114 samples ("nan": 4 % missing puts some below) take the two-sort kernel through
+    # the hand-over list.  Counters exact, mean within summation-order rounding.
+    width, height = 160, 12
+    kw = dict(nan_frac=0.0, nan_border=False, all_nan_patch=False)
+    if case == "nan":
+        kw = dict(nan_frac=0.04)
+    elif case == "hot":
+        kw.update(hot=0.3, cold=0.15)         # medians and MADs deep in the outliers
+    frames = make_frames(n, width, height, seed=8200 + n, ties=(case == "ties"), **kw)
+    frames[:, 7] = 3.25                       # constant pixel: MAD 0
+    if case != "nan":                         # (with missing samples the infinite ones could become the majority: the oracle panics then)
+        frames[n // 2 + 1:, 9] = np.inf       # just under half of the samples infinite: median and MAD still finite
+    for sl, sh in ((2.75, 2.75), (0.5, 3.0)):
+        got, gc, want, wc = run_both(nl, oracle, 4, frames, width, height, None, sl, sh, exact=False)
+        assert gc == wc, "mad n=%d %s clip counters %r vs oracle %r" % (n, case, gc, wc)
+        assert close_values(got, want), "mad n=%d %s: %s" % (n, case, describe_mismatch(got, want))
+
+
 @pytest.mark.parametrize("n", [129, 160, 200, 256, 257, 300, 384, 512])
 def test_multi_lane_linear_fit_129_to_512_frames(nl, oracle, n):
     # stack_linfit_ml_kernel: the sequential sums are chained through the 2 / 4 lanes of a pixel

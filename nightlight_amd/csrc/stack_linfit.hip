@@ -304,20 +304,26 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
                 fi += (float)CH;
             } else {
                 NL_KEEP_BRANCH;
-                static_range<c * CH, c * CH + CH>([&](auto K) NL_INL {
-                    constexpr int k = decltype(K)::value;
-                    const unsigned lbit = (live[k >> 5] >> (k & 31)) & 1u;
-                    const float g = v[k];
+                // sign bits of lb - (lin - g) and hb - (g - lin) = hb + (lin - g) (the same float:
+                // fl(g - lin) == -fl(lin - g)), shifted into one word per test with v_alignbit;
+                // liveness, counts and the mask update once per chunk
+                unsigned lowb = 0, highb = 0;
+                static_range<0, CH>([&](auto J) NL_INL {
+                    constexpr int k = c * CH + decltype(J)::value;
                     const float lin = __fadd_rn(__fmul_rn(fi, slope), icpt);
-                    const unsigned low = sign_bit(__fsub_rn(lb, __fsub_rn(lin, g))) & lbit;
-                    const unsigned high = sign_bit(__fsub_rn(hb, __fsub_rn(g, lin))) & lbit & ~low;
-                    // (opaque: integer sums may be re-associated, and the compiler would
-                    // first compute the bits of all samples and only then add them up)
-                    lo_n = opaque_u(lo_n + low);
-                    hi_n = opaque_u(hi_n + high);
-                    nlive[k >> 5] = opaque_u(nlive[k >> 5] & ~((low | high) << (k & 31)));
-                    fi += (float)lbit;
+                    const float t = __fsub_rn(lin, v[k]);
+                    lowb = __builtin_amdgcn_alignbit(lowb, (unsigned)__float_as_int(__fsub_rn(lb, t)), 31);
+                    highb = __builtin_amdgcn_alignbit(highb, (unsigned)__float_as_int(__fadd_rn(hb, t)), 31);
+                    fi += NL_AND(1.0f, NL_M(k));
                 });
+                constexpr int sh = CH * (c % CPW);
+                constexpr unsigned full = (1u << CH) - 1u;
+                const unsigned alive = (live[c / CPW] >> sh) & full;
+                const unsigned low = (__builtin_bitreverse32(lowb) >> (32 - CH)) & alive;       // sample j of the chunk at bit j
+                const unsigned high = (__builtin_bitreverse32(highb) >> (32 - CH)) & alive & ~low;
+                lo_n = opaque_u(lo_n + (unsigned)__popc(low));
+                hi_n = opaque_u(hi_n + (unsigned)__popc(high));
+                nlive[c / CPW] = opaque_u(nlive[c / CPW] & ~((low | high) << sh));
             }
         });
 #undef NL_M

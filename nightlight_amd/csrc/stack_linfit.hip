@@ -453,11 +453,25 @@ void stack_linfit_ml_kernel(StackArgs p, FastArgs q, LinfitStage g)
     bool active = on && n > 0 && !to_exact;
     int iters = 0;
 
+    // chunk classes as in the one-lane kernel: a chunk index is classified over ALL lanes of the wave
+    // (lane r of a pixel holds ranks [128 r, 128 r + 128), so the clipped ends of a column sit in the
+    // low chunks of its first and the high chunks of its last lane)
+    constexpr int CH = NL_LF_CHUNK, NC = NS / CH, CPW = 32 / CH;
     while (__any(active) && (g.max_iters == 0 || iters < g.max_iters)) {
         iters++;
         const float fm = (float)m;
         const int mt = (active && m >= 1) ? m : 1;
         const float xm = p.xstat[2 * mt], xsd = p.xstat[2 * mt + 1];
+        unsigned aa = 0, ad = 0;                // bit c: chunk c all alive / all dead in every fitting lane
+        static_range<0, NC>([&](auto C) NL_INL {
+            constexpr int c = decltype(C)::value;
+            constexpr unsigned full = (1u << CH) - 1u;
+            const unsigned byte = (live[c / CPW] >> (CH * (c % CPW))) & full;
+            aa |= (__ballot(active && byte != full) == 0ull ? 1u : 0u) << c;
+            ad |= (__ballot(active && byte != 0u) == 0ull ? 1u : 0u) << c;
+        });
+        aa = (unsigned)__builtin_amdgcn_readfirstlane((int)aa);
+        ad = (unsigned)__builtin_amdgcn_readfirstlane((int)ad);
         // survivors in the lanes before this one = index among the survivors of this lane's first
         int live_loc = 0;
         static_range<0, NW>([&](auto W) NL_INL { live_loc += __popc(live[decltype(W)::value]); });
@@ -473,15 +487,26 @@ void stack_linfit_ml_kernel(StackArgs p, FastArgs q, LinfitStage g)
             }
         }
         const float fi0 = (float)before;
-#define NL_LF(k) ((float)((live[(k) >> 5] >> ((k) & 31)) & 1u))
+#define NL_M(k) ((int)(live[(k) >> 5] << (31 - ((k) & 31))) >> 31)
+#define NL_AND(x, m) __int_as_float(__float_as_int(x) & (m))
         // ---- sum of the ys (stats.go:248-251), chained through the lanes ----
         float s = 0.0f;
         static_range<0, LPP>([&](auto J) NL_INL {
             constexpr int j = decltype(J)::value;
             float t = s;
-            static_chunks<0, NS, 16>([&](auto K) NL_INL {
-                constexpr int k = decltype(K)::value;
-                t = __fadd_rn(t, __fmul_rn(v[k], NL_LF(k)));
+            static_range<0, NC>([&](auto C) NL_INL {
+                constexpr int c = decltype(C)::value;
+                if ((ad >> c) & 1u) {
+                } else if ((aa >> c) & 1u) {
+                    NL_KEEP_BRANCH;
+                    static_range<c * CH, c * CH + CH>([&](auto K) NL_INL { t = __fadd_rn(t, v[decltype(K)::value]); });
+                } else {
+                    NL_KEEP_BRANCH;
+                    static_range<c * CH, c * CH + CH>([&](auto K) NL_INL {
+                        constexpr int k = decltype(K)::value;
+                        t = __fadd_rn(t, NL_AND(v[k], NL_M(k)));
+                    });
+                }
             });
             s = quad_from<LPP, j>(t);
             forget_words<NW>(live);
@@ -493,16 +518,33 @@ void stack_linfit_ml_kernel(StackArgs p, FastArgs q, LinfitStage g)
             constexpr int j = decltype(J)::value;
             float tv = vs, tc = corr, fi = fi0;
             const float ym2 = opaque_f(ym);
-            static_chunks<0, NS, 16>([&](auto K) NL_INL {
-                constexpr int k = decltype(K)::value;
-                const float lf = NL_LF(k);
-                const float dy = __fsub_rn(v[k], ym2);
-                const float dd = __fmul_rn(dy, dy);
-                tv = __fadd_rn(tv, __fmul_rn(dd, lf));
-                const float dx = __fsub_rn(fi, xm);
-                const float t = __fmul_rn(dx, dy);
-                tc = __fadd_rn(tc, __fmul_rn(t, lf));
-                fi += lf;
+            static_range<0, NC>([&](auto C) NL_INL {
+                constexpr int c = decltype(C)::value;
+                if ((ad >> c) & 1u) {
+                } else if ((aa >> c) & 1u) {
+                    NL_KEEP_BRANCH;
+                    const float dxb = __fsub_rn(fi, xm);          // exact, see the one-lane kernel
+                    static_range<0, CH>([&](auto U) NL_INL {
+                        constexpr int u = decltype(U)::value;
+                        const float dy = __fsub_rn(v[c * CH + u], ym2);
+                        tv = __fadd_rn(tv, __fmul_rn(dy, dy));
+                        tc = __fadd_rn(tc, __fmul_rn(__fadd_rn(dxb, (float)u), dy));
+                    });
+                    fi += (float)CH;
+                } else {
+                    NL_KEEP_BRANCH;
+                    static_range<c * CH, c * CH + CH>([&](auto K) NL_INL {
+                        constexpr int k = decltype(K)::value;
+                        const int lm = NL_M(k);
+                        const float dy = __fsub_rn(v[k], ym2);
+                        const float dd = __fmul_rn(dy, dy);
+                        tv = __fadd_rn(tv, NL_AND(dd, lm));
+                        const float dx = __fsub_rn(fi, xm);
+                        const float t = __fmul_rn(dx, dy);
+                        tc = __fadd_rn(tc, NL_AND(t, lm));
+                        fi += NL_AND(1.0f, lm);
+                    });
+                }
             });
             vs = quad_from<LPP, j>(tv);
             corr = quad_from<LPP, j>(tc);
@@ -517,17 +559,44 @@ void stack_linfit_ml_kernel(StackArgs p, FastArgs q, LinfitStage g)
         float icpt = __fsub_rn(ym, __fmul_rn(slope, xm));
         // ---- mean absolute deviation from the fit (stack.go:879-886) ----
         float sg = 0.0f;
+        float dmax[NW], dmin[NW];               // extremes of the residuals of the all-alive chunks, per 32 positions
+        static_range<0, NW>([&](auto W) NL_INL { dmax[decltype(W)::value] = -__builtin_inff(); dmin[decltype(W)::value] = __builtin_inff(); });
         static_range<0, LPP>([&](auto J) NL_INL {
             constexpr int j = decltype(J)::value;
             float t = sg, fi = fi0;
             const float sl2 = opaque_f(slope);
-            static_chunks<0, NS, 16>([&](auto K) NL_INL {
-                constexpr int k = decltype(K)::value;
-                const float lf = NL_LF(k);
-                const float lin = __fadd_rn(__fmul_rn(fi, sl2), icpt);
-                const float diff = __fsub_rn(v[k], lin);
-                t = __fadd_rn(t, __fmul_rn(fabsf(diff), lf));
-                fi += lf;
+            static_range<0, NC>([&](auto C) NL_INL {
+                constexpr int c = decltype(C)::value;
+                if ((ad >> c) & 1u) {
+                } else if ((aa >> c) & 1u) {
+                    NL_KEEP_BRANCH;
+                    float dprev = 0.0f;
+                    static_range<0, CH>([&](auto U) NL_INL {
+                        constexpr int u = decltype(U)::value;
+                        const float lin = __fadd_rn(__fmul_rn(__fadd_rn(fi, (float)u), sl2), icpt);
+                        const float diff = __fsub_rn(v[c * CH + u], lin);
+                        t = __fadd_rn(t, fabsf(diff));
+                        if constexpr (j == 0) {            // the residuals do not depend on the chain
+                            if constexpr ((u & 1) == 0) {
+                                dprev = diff;
+                            } else {
+                                dmax[c / CPW] = max3_asm(dmax[c / CPW], dprev, diff);
+                                dmin[c / CPW] = min3_asm(dmin[c / CPW], dprev, diff);
+                            }
+                        }
+                    });
+                    fi += (float)CH;
+                } else {
+                    NL_KEEP_BRANCH;
+                    static_range<c * CH, c * CH + CH>([&](auto K) NL_INL {
+                        constexpr int k = decltype(K)::value;
+                        const int lm = NL_M(k);
+                        const float lin = __fadd_rn(__fmul_rn(fi, sl2), icpt);
+                        const float diff = __fsub_rn(v[k], lin);
+                        t = __fadd_rn(t, NL_AND(fabsf(diff), lm));
+                        fi += NL_AND(1.0f, lm);
+                    });
+                }
             });
             sg = quad_from<LPP, j>(t);
             forget_words<NW>(live);
@@ -537,24 +606,46 @@ void stack_linfit_ml_kernel(StackArgs p, FastArgs q, LinfitStage g)
         float lb = __fmul_rn(p.sig_lo, sg), hb = __fmul_rn(p.sig_hi, sg);
         const bool bad = !(slope == slope) || !(icpt == icpt) || !(lb == lb) || !(hb == hb);
         if (bad) { slope = 0.0f; icpt = 0.0f; lb = __builtin_inff(); hb = __builtin_inff(); }
+        unsigned holed = 0;                     // words in which a sample of an all-alive chunk is rejected in some lane
+        static_range<0, NW>([&](auto W) NL_INL {
+            constexpr int w = decltype(W)::value;
+            holed |= (__any(active && !bad && (dmin[w] < -lb || dmax[w] > hb)) ? 1u : 0u) << w;
+        });
+        holed = (unsigned)__builtin_amdgcn_readfirstlane((int)holed);
         unsigned lo_n = 0, hi_n = 0;
         unsigned nlive[NW];
         static_range<0, NW>([&](auto W) NL_INL { nlive[decltype(W)::value] = live[decltype(W)::value]; });
         float fi = fi0;
         slope = opaque_f(slope);
-        static_chunks<0, NS, 16>([&](auto K) NL_INL {
-            constexpr int k = decltype(K)::value;
-            const unsigned lbit = (live[k >> 5] >> (k & 31)) & 1u;
-            const float g = v[k];
-            const float lin = __fadd_rn(__fmul_rn(fi, slope), icpt);
-            const unsigned low = sign_bit(__fsub_rn(lb, __fsub_rn(lin, g))) & lbit;
-            const unsigned high = sign_bit(__fsub_rn(hb, __fsub_rn(g, lin))) & lbit & ~low;
-            lo_n = opaque_u(lo_n + low);
-            hi_n = opaque_u(hi_n + high);
-            nlive[k >> 5] = opaque_u(nlive[k >> 5] & ~((low | high) << (k & 31)));
-            fi += (float)lbit;
+        static_range<0, NC>([&](auto C) NL_INL {
+            constexpr int c = decltype(C)::value;
+            if ((ad >> c) & 1u) {
+            } else if (((aa >> c) & 1u) && !((holed >> (c / CPW)) & 1u)) {
+                NL_KEEP_BRANCH;
+                fi += (float)CH;
+            } else {
+                NL_KEEP_BRANCH;
+                unsigned lowb = 0, highb = 0;
+                static_range<0, CH>([&](auto U) NL_INL {
+                    constexpr int k = c * CH + decltype(U)::value;
+                    const float lin = __fadd_rn(__fmul_rn(fi, slope), icpt);
+                    const float t = __fsub_rn(lin, v[k]);
+                    lowb = __builtin_amdgcn_alignbit(lowb, (unsigned)__float_as_int(__fsub_rn(lb, t)), 31);
+                    highb = __builtin_amdgcn_alignbit(highb, (unsigned)__float_as_int(__fadd_rn(hb, t)), 31);
+                    fi += NL_AND(1.0f, NL_M(k));
+                });
+                constexpr int sh = CH * (c % CPW);
+                constexpr unsigned full = (1u << CH) - 1u;
+                const unsigned alive = (live[c / CPW] >> sh) & full;
+                const unsigned low = (__builtin_bitreverse32(lowb) >> (32 - CH)) & alive;
+                const unsigned high = (__builtin_bitreverse32(highb) >> (32 - CH)) & alive & ~low;
+                lo_n = opaque_u(lo_n + (unsigned)__popc(low));
+                hi_n = opaque_u(hi_n + (unsigned)__popc(high));
+                nlive[c / CPW] = opaque_u(nlive[c / CPW] & ~((low | high) << sh));
+            }
         });
-#undef NL_LF
+#undef NL_M
+#undef NL_AND
         const int lo_all = quad_sum<LPP>((int)lo_n), hi_all = quad_sum<LPP>((int)hi_n);
         if (active) {
             p_lo += lo_all;
@@ -615,6 +706,22 @@ int linfit_ml_supported(int mode, int n_frames, int64_t npix)
     return (mode == NL_ST_LINEAR_FIT && n_frames > 128 && n_frames <= 512 && npix < ((int64_t)1 << 27)) ? 1 : 0;
 }
 
+// fit iterations per cascade stage (the last stage runs to the end); NL_LF_QUOTA="a,b,c" overrides
+// the first three for tuning runs
+static const int *linfit_quota()
+{
+    static int quota[kLinfitStages] = {8, 6, 8, 0};     // measured: 19.7 ms vs 20.2 (6,6,8), 20.4 (10,8,8), 21.1 (5,5,8) on 128 x 4096^2
+    static bool parsed = false;
+    if (!parsed) {
+        parsed = true;
+        if (const char *e = getenv("NL_LF_QUOTA")) {
+            int a = 0, b = 0, c = 0;
+            if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { quota[0] = a; quota[1] = b; quota[2] = c; }
+        }
+    }
+    return quota;
+}
+
 template <int LPP>
 static void launch_lf_ml(const StackArgs &args, const FastArgs &f, const LinfitCascade *c, hipStream_t stream,
                          hipEvent_t dominant_done)
@@ -627,7 +734,7 @@ static void launch_lf_ml(const StackArgs &args, const FastArgs &f, const LinfitC
         if (dominant_done) (void)hipEventRecord(dominant_done, stream);
         return;
     }
-    static const int quota[kLinfitStages] = {6, 6, 8, 0};        // as the one-lane kernel
+    const int *quota = linfit_quota();                          // as the one-lane kernel
     for (int s = 0; s < kLinfitStages; s++) {
         g.max_iters = quota[s];
         g.in_list = s ? c->list[(s - 1) & 1] : nullptr;
@@ -665,22 +772,6 @@ hipError_t launch_stack_linfit_ml(const StackArgs &args, const FastArgs &fargs, 
 int linfit_fast_supported(int mode, int n_frames, int64_t npix)
 {
     return (mode == NL_ST_LINEAR_FIT && n_frames >= 1 && n_frames <= 128 && npix < kFastMaxPixels) ? 1 : 0;
-}
-
-// fit iterations per cascade stage (the last stage runs to the end); NL_LF_QUOTA="a,b,c" overrides
-// the first three for tuning runs
-static const int *linfit_quota()
-{
-    static int quota[kLinfitStages] = {8, 6, 8, 0};     // measured: 19.7 ms vs 20.2 (6,6,8), 20.4 (10,8,8), 21.1 (5,5,8) on 128 x 4096^2
-    static bool parsed = false;
-    if (!parsed) {
-        parsed = true;
-        if (const char *e = getenv("NL_LF_QUOTA")) {
-            int a = 0, b = 0, c = 0;
-            if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { quota[0] = a; quota[1] = b; quota[2] = c; }
-        }
-    }
-    return quota;
 }
 
 template <int NS>

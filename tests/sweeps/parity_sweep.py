@@ -22,6 +22,7 @@ CASES = [  # mode, frames, width, rows, weighted
     (2, 128, 4096, 128, True), (3, 96, 4096, 128, True),
     (4, 100, 4096, 512, False), (4, 256, 4096, 128, False), (5, 256, 4096, 64, False), (5, 400, 4096, 32, False),
     (0, 512, 4096, 128, False), (0, 200, 4096, 256, False), (2, 600, 4096, 32, False), (0, 600, 4096, 32, False),
+    (4, 128, 4096, 512, False), (4, 120, 4096, 256, False), (5, 120, 4096, 128, False), (3, 100, 4096, 256, False),
 ]
 bad = 0
 for seed in (11, 12, 13):

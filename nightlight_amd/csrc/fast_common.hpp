@@ -14,6 +14,17 @@ constexpr int kZone = 8;      // sorted positions per side that may be clipped i
 constexpr int kPadMax = 8;    // missing samples (NaN) a lane may have in the zonal path
 constexpr unsigned kGenericGrid = 2048;   // workgroups of the generic pass over the hand-over list
 
+// A generic pass appends to the exact-replay list while the first replay may already be reading it:
+// before its first append every workgroup makes sure the list's length as the dominant kernel left it
+// is on record (StackArgs::list_snap; the first to look -- of this pass or of the replay -- wins).
+__device__ __forceinline__ void snapshot_fb_list(const FastArgs &q)
+{
+    // (a plain look first: thousands of workgroups hitting one address with atomics take 0.5 ms)
+    if (q.fb_snap && threadIdx.x == 0 && __atomic_load_n(q.fb_snap, __ATOMIC_RELAXED) == 0u)
+        (void)atomicCAS(q.fb_snap, 0u, *q.fb_count + 1u);
+    __syncthreads();
+}
+
 // compile-time loops: every index is a constant, so register columns never
 // fall back to scratch memory (pragma unroll gives up on the large networks)
 template <int B, int... I, class F>

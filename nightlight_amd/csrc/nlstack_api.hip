@@ -525,7 +525,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
     a.list = nullptr;
     a.list_count = nullptr;
     a.list_capacity = 0;
-    a.list_begin = nullptr;
+    a.list_snap = nullptr;
+    a.list_part = 0;
 
     {
         const int slot = (int)(h->pass_seq % kTimingRing);
@@ -646,6 +647,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         f.fb_list = h->d_fb_list;
         f.fb_count = h->d_fb_count;
         f.fb_capacity = (unsigned)h->npix;
+        f.fb_snap = h->d_fb_count + 2;               // see the replay below
         f.gen_list = h->d_gen_list;
         f.gen_count = h->d_fb_count + 1;
         f.gen_capacity = (unsigned)h->npix;
@@ -661,18 +663,18 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         e.list_count = h->d_fb_count;
         e.list_capacity = (unsigned)h->npix;
         const bool coop = nl::coop_supported(mode, weighted, a.n_frames) != 0;
-        unsigned *snap = h->d_fb_count + 2;               // list length when the dominant kernel is done
+        unsigned *snap = h->d_fb_count + 2;               // 1 + list length when the first replay started (set on the device)
         struct Fork { nl_stack *h; nl::StackArgs e; int mode; unsigned *snap; hipError_t err; } fork{h, e, mode, snap, hipSuccess};
         nl::AfterDominant after = nullptr;
         if (coop) after = [](void *u) {
             Fork *k = static_cast<Fork *>(u);
             nl_stack *hh = k->h;
             const char *ignored = "";
-            hipError_t err = hipMemcpyAsync(k->snap, hh->d_fb_count, sizeof(unsigned), hipMemcpyDeviceToDevice, hh->stream);
-            if (err == hipSuccess) err = hipEventRecord(hh->ev_fork, hh->stream);
+            hipError_t err = hipEventRecord(hh->ev_fork, hh->stream);
             if (err == hipSuccess) err = hipStreamWaitEvent(hh->side_stream, hh->ev_fork, 0);
             nl::StackArgs first = k->e;
-            first.list_count = k->snap;
+            first.list_snap = k->snap;                    // the list as the dominant kernel left it (snapshot on the device)
+            first.list_part = 0;
             if (err == hipSuccess) err = nl::launch_stack_sigma_coop(k->mode, first, kCoopGrid, hh->side_stream, &ignored);
             if (err == hipSuccess) err = hipEventRecord(hh->ev_join, hh->side_stream);
             k->err = err;
@@ -686,7 +688,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         NL_HIP(fork.err);
         const char *exact_name = "";
         if (coop) {
-            e.list_begin = snap;                          // the generic pass's additions
+            e.list_snap = snap;                           // the generic pass's additions
+            e.list_part = 1;
             NL_HIP(nl::launch_stack_sigma_coop(mode, e, kCoopGrid / 4, h->stream, &exact_name));
             NL_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         } else {

@@ -176,7 +176,19 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
     long long c_lo = 0, c_hi = 0;
 
     int64_t first = 0;
-    if (p.list && p.list_begin) first = min((int64_t)*p.list_begin, limit);
+    if (p.list && p.list_snap) {
+        unsigned s = 0;
+        if (lane == 0) {
+            s = __atomic_load_n(p.list_snap, __ATOMIC_RELAXED);        // (a plain look first: one address, thousands of workgroups)
+            if (s == 0u) {
+                s = atomicCAS(p.list_snap, 0u, (unsigned)limit + 1u);
+                if (s == 0u) s = (unsigned)limit + 1u;
+            }
+        }
+        s = (unsigned)__shfl((int)s, 0, 64);
+        const int64_t snap = min((int64_t)(s - 1u), limit);
+        if (p.list_part == 0) limit = snap; else first = snap;
+    }
     for (int64_t item = first + blockIdx.x; item < limit; item += gridDim.x) {
         const int64_t pix = p.list ? (int64_t)p.list[item] : item;
         const float *fr = p.frames + pix;

@@ -373,6 +373,7 @@ template <int NS, bool ZONAL, bool WINSOR, bool TIGHT>
 __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
 {
     static_assert(!TIGHT || ZONAL, "TIGHT is a variant of the zonal kernels");
+    if constexpr (!ZONAL) { if (q.in_list) snapshot_fb_list(q); }
     // zone widths: 8 clipped + 8 missing samples per lane for the larger
     // networks, 4 + 4 for the small ones
     constexpr int KZ = NS >= 48 ? kZone : 4, KP = TIGHT ? 0 : (NS >= 48 ? kPadMax : 4);

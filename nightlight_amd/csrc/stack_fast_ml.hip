@@ -52,6 +52,7 @@ template <int LPP, bool ZONAL, bool WINSOR, bool WIDE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZONAL ? (WINSOR ? 2 : 3) : 1, 8)))
 void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
 {
+    if constexpr (!ZONAL) { if (q.in_list) snapshot_fb_list(q); }
     constexpr int NS = kMlNS, NT = NS * LPP;
     constexpr int ZL = kZone;                        // low zone : ranks [0, ZL)           (role 0)
     static_assert(!WIDE || ZONAL, "WIDE is a zonal variant");

@@ -148,6 +148,7 @@ void stack_sigma_mlg_kernel(StackArgs p, FastArgs q)
     using LY = MlgLayout<LPP>;
     constexpr int NS = LY::NS, NT = LY::NT, PW = LY::PW;
     __shared__ float lds[LY::ROWS * PW];
+    if (q.in_list) snapshot_fb_list(q);
 
     const int lane = threadIdx.x & 63;
     const int role = threadIdx.x % LPP;
@@ -238,8 +239,8 @@ void stack_sigma_mlg_kernel(StackArgs p, FastArgs q)
             const int cnt = b - a;
             const float fcnt = (float)cnt;
             const float inv_cnt = 1.0f / fcnt;
-            const int kk = min(max(a + (cnt >> 1), 1), top);
-            const float upper = x[kk * PW], lower = x[(kk - 1) * PW];
+            const int kk = min(max(a + (cnt >> 1), 0), top);       // (a single survivor: rank a itself)
+            const float upper = x[kk * PW], lower = x[max(kk - 1, 0) * PW];
             const float median = (cnt & 1) ? upper : 0.5f * (lower + upper);       // qsort.go:68-82
             const float xmin = x[min(max(a, 0), top) * PW], xmax = x[min(max(b - 1, 0), top) * PW];
 

@@ -28,7 +28,12 @@ struct StackArgs {
     const unsigned *list;         // optional: pixel indices to process instead of 0..npix-1
     const unsigned *list_count;   // device-side length of `list`
     unsigned list_capacity;
-    const unsigned *list_begin;   // device-side first item to process (nullptr: 0); wave-per-pixel replay only
+    // wave-per-pixel replay only: a cell (zero before the pass) shared by the two replays of a pass.  The
+    // first workgroup of either to look stores 1 + the list's length at that moment; part 0 replays the
+    // items before that snapshot (what the dominant kernel handed over), part 1 the items from it on
+    // (what the generic pass added) -- no host-enqueued snapshot copy between the kernels
+    unsigned *list_snap;
+    int list_part;
 };
 
 // fallback list written by the fast kernels, consumed by the exact kernel
@@ -36,6 +41,7 @@ struct FastArgs {
     unsigned *fb_list;            // [fb_capacity] pixels for the exact kernel
     unsigned *fb_count;           // device counter, zeroed before every pass
     unsigned fb_capacity;
+    unsigned *fb_snap;            // optional, see StackArgs::list_snap: a generic pass stores 1 + *fb_count here before it appends
     unsigned *gen_list;           // [gen_capacity] pixels a zonal wave hands to the generic pass
     unsigned *gen_count;          // device counter, zeroed before every pass
     unsigned gen_capacity;

@@ -583,6 +583,23 @@ def test_register_resident_mad_counts_exact_values_close(nl, oracle, n):
         assert close_values(got, want), "mad n=%d: %s" % (n, describe_mismatch(got, want))
 
 
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("n", [70, 125, 128, 200, 300, 512])
+def test_pixels_with_one_two_or_three_samples(nl, oracle, mode, n):
+    # pixels that keep 1, 2 or 3 valid samples (aligned frames' corners) go to the generic pass on LDS
+    # columns (stack_fast_mlg.hip): a single survivor is its own median and clips nothing
+    # (found by tests/sweeps/fuzz_parity.py seed 62, case 3720)
+    width, height = 64, 3
+    frames = make_frames(n, width, height, seed=9300 + n, nan_frac=0.0, nan_border=False, all_nan_patch=False)
+    for keep in (1, 2, 3):
+        for k, p in enumerate(range(5 * keep, 5 * keep + 4)):
+            frames[:, p] = np.nan
+            frames[(7 * k + np.arange(keep) * 11) % n, p] = (1136.0, 900.0, 1500.0)[:keep]
+    got, gc, want, wc = run_both(nl, oracle, mode, frames, width, height, None, 0.74, 2.08, exact=False)
+    assert gc == wc, "%s n=%d clip counters %r vs oracle %r" % (MODES[mode], n, gc, wc)
+    assert close_values(got, want), "%s n=%d: %s" % (MODES[mode], n, describe_mismatch(got, want))
+
+
 @pytest.mark.parametrize("n", [114, 115, 121, 127, 128])
 @pytest.mark.parametrize("case", ["clean", "nan", "ties", "hot"])
 def test_mad_selection_kernel_114_to_128_frames(nl, oracle, n, case):

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void stack_median_fast_kernel(StackArgs p, Fas
 // (for some inputs it runs off the array and panics).  Such a pixel goes to the exact
 // kernel, which follows the reference step by step where that is defined.
 template <int NS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS > 96 ? 3 : 1, 8)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS > 80 ? 3 : 1, 8)))   // (96: 190 VGPRs otherwise, since the 128-position merge)
 void stack_mad_fast_kernel(StackArgs p, FastArgs q)
 {
     // q.in_list: the pixels stack_mad_bitonic_kernel handed over (the list's length is only known on
@@ -146,13 +146,28 @@ void stack_mad_fast_kernel(StackArgs p, FastArgs q)
     const float median = (n & 1) ? upper : 0.5f * (lower + upper);
     const bool degenerate = n > 0 && !(__builtin_fabsf(median) < __builtin_inff());
     const float msafe = degenerate ? 0.0f : median;
-    static_chunks<0, NS, 16>([&](auto K) NL_INL {
-        constexpr int k = decltype(K)::value;
-        v[k] = __builtin_fabsf(v[k] - msafe);                // stack.go:566-571 (pads stay +Inf)
-    });
-    sort_network<NS, false>(v);
     float dupper, dlower;
-    pick_pair<0, NS>(v, kk, dlower, dupper);
+    if constexpr (NS > 64) {
+        // the deviations of a sorted column fall to the median and rise again (pads: +Inf on top): a
+        // bitonic sequence, which the half-cleaner cascade of a bitonic merge sorts -- 626 fused
+        // operations on 128 positions (FusedBitonic, sort_tables.inc) instead of a second sorting
+        // network (1 500 .. 2 184)
+        float d[128];
+        static_chunks<0, 128, 16>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            if constexpr (k < NS) d[k] = __builtin_fabsf(v[k] - msafe);          // stack.go:566-571 (pads stay +Inf)
+            else                  d[k] = __builtin_inff();
+        });
+        run_network<FusedBitonic<128, 0>, 128>(d);
+        pick_pair<0, NS>(d, kk, dlower, dupper);
+    } else {
+        static_chunks<0, NS, 16>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            v[k] = __builtin_fabsf(v[k] - msafe);            // stack.go:566-571 (pads stay +Inf)
+        });
+        sort_network<NS, false>(v);
+        pick_pair<0, NS>(v, kk, dlower, dupper);
+    }
     const float mad = (n & 1) ? dupper : 0.5f * (dlower + dupper);
     const float sd = mad * 1.4826f;                          // stack.go:574
     const float t_lo = p.sig_lo * sd, t_hi = p.sig_hi * sd;

@@ -470,7 +470,7 @@ hipError_t launch_stack_median_ml(const StackArgs &args, hipStream_t stream, con
 }
 
 // StackMADSigma (stack.go:536-605) for 129..512 frames, as stack_mad_fast_kernel: merged
-// column -> median; column := |x - median| -> sort + merge again -> MAD; second read of the
+// column -> median; column := |x - median| -> bitonic merge -> MAD; second read of the
 // pixel's frames (every lane its own) for the clip counts and the mean of the survivors.
 template <int LPP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8)))
@@ -495,7 +495,13 @@ void stack_mad_ml_kernel(StackArgs p, FastArgs q)
         constexpr int k = decltype(K)::value;
         v[k] = __builtin_fabsf(v[k] - msafe);
     });
-    ml_sort_merge<LPP, NS, false>(v, role);
+    // The deviations of the sorted column (lane r: ranks [128 r, 128 r + 128)) fall to the median and rise
+    // again, +Inf pads on top: ONE bitonic sequence over the lanes of the pixel.  The half-cleaner cascade
+    // of a bitonic merge sorts it -- lane distance 2 and 1 (element i meets the partner's element i), then
+    // the in-lane cascade -- without the 2 184-operation sort of every lane and the run merges.
+    if constexpr (LPP == 4) cross_stage<NS, kSwap2, false>(v, role < 2);
+    cross_stage<NS, kSwap1, false>(v, (role & 1) == 0);
+    run_network<FusedBitonic<NS, 0>, NS>(v);
     const float dupper = pick_rank<LPP, NS, NS, NS>(v, kk, role, 0);
     const float dlower = pick_rank<LPP, NS, NS, NS>(v, kk > 0 ? kk - 1 : 0, role, 0);
     const float mad = (n & 1) ? dupper : 0.5f * (dlower + dupper);

@@ -168,11 +168,18 @@ void stack_sigma_mlg_kernel(StackArgs p, FastArgs q)
         int64_t pix = item;
         if (q.in_list) pix = on ? (int64_t)q.in_list[item] : 0;
 
+#ifdef NL_ROUND_STATS
+        const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
         float v[NS];
         int n;
         if constexpr (LPP == 1) n = gather_sorted<NS, NS>(p.frames, p.stride, N, (unsigned)(on ? pix : 0) * 4u, v);
         else                    n = ml_gather_sorted<LPP, NS, false>(p.frames, p.stride, N, on, pix, role, v);
 
+#ifdef NL_ROUND_STATS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long t1 = __builtin_readcyclecounter();
+#endif
         // ---- the whole column to LDS: lane r holds ranks [r NS, r NS + NS) ----
         {
             float *mine = col + (LY::X + role * NS) * PW;
@@ -227,6 +234,9 @@ void stack_sigma_mlg_kernel(StackArgs p, FastArgs q)
         }
         lds_settle_g();
 
+#ifdef NL_ROUND_STATS
+        const unsigned long long t2 = __builtin_readcyclecounter();
+#endif
         float res = p.ref_loc;
         int c_lo = 0, c_hi = 0;
         int a = 0, b = n;                                  // survivors = sorted ranks [a, b)
@@ -351,6 +361,12 @@ void stack_sigma_mlg_kernel(StackArgs p, FastArgs q)
             }
         }
 
+#ifdef NL_ROUND_STATS
+        if (lane == 0) {
+            const unsigned long long t3 = __builtin_readcyclecounter();
+            NL_STAT(5, t1 - t0); NL_STAT(6, t2 - t1); NL_STAT(7, t3 - t2);
+        }
+#endif
         const bool rep = on && role == 0;
         if (rep && !to_exact) {
             p.out[pix] = res;

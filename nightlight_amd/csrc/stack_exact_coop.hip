@@ -78,7 +78,7 @@ __device__ __forceinline__ float seq_sum(int n, F &&elem)
 // s = #{i : L_i < R_i} the pass performs the swaps i < s -- disjoint positions,
 // so they can be done in parallel -- and ends with r = max(R_s, L_{s-1}).
 // The resulting array is identical to the sequential one, element for element.
-__device__ float coop_select(float *a, int *lpos, int *rfwd, int n, int k)
+__device__ float coop_select(float *a, unsigned short *lpos, unsigned short *rfwd, int n, int k)
 {
     const int lane = threadIdx.x;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -94,8 +94,8 @@ __device__ float coop_select(float *a, int *lpos, int *rfwd, int n, int k)
             const bool isl = in && x >= pivot;
             const bool isr = in && x <= pivot;
             const unsigned long long ml = __ballot(isl), mr = __ballot(isr);
-            if (isl) lpos[nl + __popcll(ml & below)] = idx;
-            if (isr) rfwd[nr + __popcll(mr & below)] = idx;        // ascending; R_i = rfwd[nr-1-i]
+            if (isl) lpos[nl + __popcll(ml & below)] = (unsigned short)idx;         // (positions < 65536 by coop_supported: 16 bits, half the LDS)
+            if (isr) rfwd[nr + __popcll(mr & below)] = (unsigned short)idx;         // ascending; R_i = rfwd[nr-1-i]
             nl += __popcll(ml);
             nr += __popcll(mr);
         }
@@ -105,7 +105,7 @@ __device__ float coop_select(float *a, int *lpos, int *rfwd, int n, int k)
         int s_cnt = 0;
         for (int base = 0; base < pairs; base += 64) {
             const int i = base + lane;
-            const bool ok = i < pairs && lpos[i] < rfwd[nr - 1 - i];
+            const bool ok = i < pairs && (int)lpos[i] < (int)rfwd[nr - 1 - i];
             const unsigned long long m = __ballot(ok);
             s_cnt += __popcll(m);
             if (m != ~0ull) break;
@@ -114,14 +114,14 @@ __device__ float coop_select(float *a, int *lpos, int *rfwd, int n, int k)
         for (int base = 0; base < s_cnt; base += 64) {
             const int i = base + lane;
             if (i < s_cnt) {
-                const int pl = lpos[i], pr = rfwd[nr - 1 - i];
+                const int pl = (int)lpos[i], pr = (int)rfwd[nr - 1 - i];
                 const float xl = a[pl], xr = a[pr];
                 a[pl] = xr;
                 a[pr] = xl;
             }
         }
-        const int r_next = s_cnt < nr ? rfwd[nr - 1 - s_cnt] : -1;
-        const int l_prev = s_cnt > 0 ? lpos[s_cnt - 1] : -1;
+        const int r_next = s_cnt < nr ? (int)rfwd[nr - 1 - s_cnt] : -1;
+        const int l_prev = s_cnt > 0 ? (int)lpos[s_cnt - 1] : -1;
         const int r = max(r_next, l_prev);
         lds_fence();
         const int offset = r - left + 1;
@@ -136,7 +136,7 @@ __device__ float coop_select(float *a, int *lpos, int *rfwd, int n, int k)
 }
 
 // qsort.go:68-82
-__device__ float coop_select_median(float *a, int *lpos, int *rfwd, int n)
+__device__ float coop_select_median(float *a, unsigned short *lpos, unsigned short *rfwd, int n)
 {
     const int k = (n >> 1) + 1;
     const float upper = coop_select(a, lpos, rfwd, n, k);
@@ -164,8 +164,8 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
     extern __shared__ float a[];
     float *wz = a + p.n_frames;                   // winsorized copy (WINSOR only)
     float *wt = a + (WINSOR ? 2 : 1) * p.n_frames;          // weights (W only)
-    int *lpos = reinterpret_cast<int *>(a + ((WINSOR ? 2 : 1) + (W ? 1 : 0)) * p.n_frames);   // partition scratch, 2 x n_frames
-    int *rfwd = lpos + p.n_frames;
+    unsigned short *lpos = reinterpret_cast<unsigned short *>(a + ((WINSOR ? 2 : 1) + (W ? 1 : 0)) * p.n_frames);   // partition scratch, 2 x n_frames x 16 bit
+    unsigned short *rfwd = lpos + p.n_frames;
     const int lane = threadIdx.x;
     const int N = p.n_frames;
     int64_t limit = p.npix;
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
 __global__ __launch_bounds__(64) void stack_median_coop_kernel(StackArgs p)
 {
     extern __shared__ float a[];
-    int *lpos = reinterpret_cast<int *>(a + p.n_frames);
-    int *rfwd = lpos + p.n_frames;
+    unsigned short *lpos = reinterpret_cast<unsigned short *>(a + p.n_frames);
+    unsigned short *rfwd = lpos + p.n_frames;
     const int lane = threadIdx.x;
     const int N = p.n_frames;
     for (int64_t pix = blockIdx.x; pix < p.npix; pix += gridDim.x) {
@@ -331,21 +331,21 @@ __global__ __launch_bounds__(64) void stack_median_coop_kernel(StackArgs p)
 hipError_t launch_stack_median_coop(const StackArgs &args, int grid, hipStream_t stream, const char **name)
 {
     *name = "stack_median_coop_kernel";
-    hipLaunchKernelGGL(stack_median_coop_kernel, dim3(grid), dim3(64), (size_t)args.n_frames * 3 * sizeof(float), stream,
+    hipLaunchKernelGGL(stack_median_coop_kernel, dim3(grid), dim3(64), (size_t)args.n_frames * 2 * sizeof(float), stream,
                        args);
     return hipGetLastError();
 }
 
 static size_t coop_columns(int mode, bool weighted)
 {
-    return (mode == NL_ST_WINSOR_SIGMA ? 2 : 1) + (weighted ? 1 : 0) + 2;      // samples (+copy) (+weights) + 2 scratch
+    return (mode == NL_ST_WINSOR_SIGMA ? 2 : 1) + (weighted ? 1 : 0) + 1;      // samples (+copy) (+weights) + 2 scratch columns of 16 bits
 }
 
 int coop_supported(int mode, bool weighted, int n_frames)
 {
-    if (mode == NL_ST_MEDIAN) return (size_t)n_frames * 3 * sizeof(float) <= 64 * 1024 ? 1 : 0;
+    if (mode == NL_ST_MEDIAN) return (n_frames <= 65535 && (size_t)n_frames * 2 * sizeof(float) <= 64 * 1024) ? 1 : 0;
     if (mode != NL_ST_SIGMA && mode != NL_ST_WINSOR_SIGMA) return 0;
-    return (size_t)n_frames * coop_columns(mode, weighted) * sizeof(float) <= 64 * 1024 ? 1 : 0;
+    return (n_frames <= 65535 && (size_t)n_frames * coop_columns(mode, weighted) * sizeof(float) <= 64 * 1024) ? 1 : 0;
 }
 
 hipError_t launch_stack_sigma_coop(int mode, const StackArgs &args, int grid, hipStream_t stream, const char **name)

@@ -20,8 +20,17 @@ constexpr unsigned kGenericGrid = 2048;   // workgroups of the generic pass over
 __device__ __forceinline__ void snapshot_fb_list(const FastArgs &q)
 {
     // (a plain look first: thousands of workgroups hitting one address with atomics take 0.5 ms)
-    if (q.fb_snap && threadIdx.x == 0 && __atomic_load_n(q.fb_snap, __ATOMIC_RELAXED) == 0u)
-        (void)atomicCAS(q.fb_snap, 0u, *q.fb_count + 1u);
+    // Ordering: the CAS is a RETURNING atomic whose value is consumed, so it has been performed at L2
+    // (device scope) before this thread goes on; the fence orders it before the barrier, and no wave of
+    // this workgroup appends (atomicAdd on fb_count) before the barrier.  The length itself is read with
+    // an atomic load: appends of OTHER workgroups may be in flight, but each of them has recorded the
+    // snapshot before its first append, so whoever wins the CAS read a count no append had touched.
+    if (q.fb_snap && threadIdx.x == 0 && __atomic_load_n(q.fb_snap, __ATOMIC_RELAXED) == 0u) {
+        const unsigned len = __atomic_load_n(q.fb_count, __ATOMIC_RELAXED);
+        const unsigned prev = atomicCAS(q.fb_snap, 0u, len + 1u);
+        if (prev == 0xffffffffu) __builtin_trap();           // (never: keeps the returning form)
+        __threadfence();
+    }
     __syncthreads();
 }
 

@@ -201,11 +201,13 @@ __global__ __launch_bounds__(256) void median_mask_kernel(const float *in, float
     if (i >= n) return;
     float x[kMaskMax];
     int num = 0;
+    bool has_nan = false;
 #pragma unroll
     for (int j = 0; j < kMaskMax; j++) {
         const int64_t io = i + m.off[j];
         const bool ok = j < len && io >= 0 && io < n;
         x[j] = ok ? in[io] : __builtin_inff();          // missing: +Inf, never the k-th smallest for k < num
+        has_nan |= x[j] != x[j];
         num += ok ? 1 : 0;
     }
     const int ku = num >> 1, kl = ku - 1;
@@ -223,6 +225,10 @@ __global__ __launch_bounds__(256) void median_mask_kernel(const float *in, float
     }
     float res = (num & 1) ? upper : 0.5f * (lower + upper);
     if (num == 0) res = __builtin_nanf("");                 // median3x3.go:116
+    // The reference requires NaN-free input (median3x3.go:114: its quickselect does not terminate
+    // properly on NaN).  Counting would match no rank and return a wrong value silently: a
+    // neighbourhood holding a NaN yields NaN instead.
+    if (has_nan) res = __builtin_nanf("");
     out[i] = res;
 }
 

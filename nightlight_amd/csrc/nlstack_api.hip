@@ -30,6 +30,13 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+}  // namespace
+
+// the thread's error message, for the other translation units of the library (nlstack_group.hip)
+namespace nl { void set_last_error(const char *msg) { g_err = msg ? msg : ""; } }
+
+namespace {
+
 #define NL_HIP(call)                                                                        \
     do {                                                                                    \
         hipError_t e_ = (call);                                                             \

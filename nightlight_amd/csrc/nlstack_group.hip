@@ -128,17 +128,27 @@ int nl_group_run(nl_group_t *g, int mode, float sigma_low, float sigma_high, flo
                  float *out_host, int64_t *clip_low, int64_t *clip_high)
 {
     if (!g) return NL_ERR_INVALID_ARG;
-    for (size_t t = 0; t < g->tiles.size(); t++) {
-        int rc = nl_stack_run_async(g->tiles[t], mode, sigma_low, sigma_high, ref_loc);
-        if (rc != NL_OK) return rc;
-    }
+    // A failing tile must not leave the other tiles' passes enqueued and pending: every pass that was
+    // started is also finished, and the FIRST error (with its message) is what the caller gets.
+    int first_rc = NL_OK;
+    std::string first_msg;
+    auto note = [&](int rc) {
+        if (rc != NL_OK && first_rc == NL_OK) { first_rc = rc; first_msg = nl_last_error(); }
+    };
+    size_t started = 0;
+    for (; started < g->tiles.size() && first_rc == NL_OK; started++)
+        note(nl_stack_run_async(g->tiles[started], mode, sigma_low, sigma_high, ref_loc));
+    if (first_rc != NL_OK) started--;                     // the failing tile enqueued nothing to wait for
     int64_t lo = 0, hi = 0;
-    for (size_t t = 0; t < g->tiles.size(); t++) {
+    for (size_t t = 0; t < started; t++) {
         int64_t l = 0, h = 0;
-        int rc = nl_stack_finish(g->tiles[t], out_host, &l, &h);
-        if (rc != NL_OK) return rc;
+        note(nl_stack_finish(g->tiles[t], first_rc == NL_OK ? out_host : nullptr, &l, &h));
         lo += l;                                          // stack.go:193-198
         hi += h;
+    }
+    if (first_rc != NL_OK) {
+        nl::set_last_error(first_msg.c_str());
+        return first_rc;
     }
     if (clip_low) *clip_low = lo;
     if (clip_high) *clip_high = hi;

@@ -170,7 +170,8 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
     const int N = p.n_frames;
     int64_t limit = p.npix;
     if (p.list) {
-        const unsigned cnt = *p.list_count;
+        // atomic load: a generic pass on another stream may be appending (see snapshot_fb_list, fast_common.hpp)
+        const unsigned cnt = __atomic_load_n(p.list_count, __ATOMIC_RELAXED);
         limit = cnt < p.list_capacity ? cnt : p.list_capacity;
     }
     long long c_lo = 0, c_hi = 0;

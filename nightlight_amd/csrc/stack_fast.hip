@@ -914,11 +914,17 @@ static const char *sigma_kernel_name()
     return name.c_str();
 }
 
+// The nested launchers (stack_fast_mlg.hip, stack_fast_mlz.hip) end in hipGetLastError(), which CLEARS
+// the pending error: their result is kept here (first error wins) so that a failed launch of the
+// dominant kernel or of the generic pass reaches nl_stack_run instead of being erased.
+static inline void keep_first(hipError_t &acc, hipError_t e) { if (acc == hipSuccess) acc = e; }
+
 template <int NS, bool WINSOR>
-static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned tile_blocks,
-                        hipStream_t stream, const char **name, hipEvent_t dominant_done,
-                        AfterDominant after, void *user)
+static hipError_t launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned tile_blocks,
+                              hipStream_t stream, const char **name, hipEvent_t dominant_done,
+                              AfterDominant after, void *user)
 {
+    hipError_t err = hipSuccess;
     FastArgs f = fargs;
     f.in_list = nullptr;
     f.in_count = nullptr;
@@ -933,7 +939,8 @@ static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned t
             hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true, WINSOR, false>), dim3(tile_blocks), dim3(256), 0,
                                stream, args, f);
         }
-        if (dominant_done) (void)hipEventRecord(dominant_done, stream);
+        keep_first(err, hipGetLastError());
+        if (dominant_done) keep_first(err, hipEventRecord(dominant_done, stream));
         if (after) after(user);
         // generic pass over the pixels the zonal waves handed over (its length
         // is only known on the device: fixed grid, grid-stride loop)
@@ -946,48 +953,52 @@ static void launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned t
             // is a few LDS reads instead of a pass over 128 masked registers -- this pass is pure
             // latency (a few hundred waves at most), and it sits on every pass's critical path
             const unsigned lblocks = 4 * tile_blocks < 4 * kGenericGrid ? 4 * tile_blocks : 4 * kGenericGrid;
-            (void)launch_stack_sigma_mlg(args, f, lblocks, stream, WINSOR);
+            keep_first(err, launch_stack_sigma_mlg(args, f, lblocks, stream, WINSOR));
         } else {
             hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false, WINSOR, false>), dim3(gblocks), dim3(256), 0,
                                stream, args, f);
+            keep_first(err, hipGetLastError());
         }
     } else {
         // small stacks: generic passes are cheap, run them over the whole tile
         *name = sigma_kernel_name<NS, false, WINSOR, false>();
         hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false, WINSOR, false>), dim3(tile_blocks), dim3(256), 0,
                            stream, args, f);
-        if (dominant_done) (void)hipEventRecord(dominant_done, stream);
+        keep_first(err, hipGetLastError());
+        if (dominant_done) keep_first(err, hipEventRecord(dominant_done, stream));
         if (after) after(user);
     }
+    return err;
 }
 
 template <bool WINSOR>
-static void launch_sized(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name,
+static hipError_t launch_sized(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name,
                          hipEvent_t dominant_done, AfterDominant after, void *user)
 {
     const unsigned blocks = (unsigned)((args.npix + 255) / 256);
     const int n = args.n_frames;
     // network sizes: the frame count rounded up to the next instantiated size;
     // unused positions count as missing samples
-    if (n <= 8)        launch_pair<8, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else if (n <= 16)  launch_pair<16, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else if (n <= 24)  launch_pair<24, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else if (n <= 32)  launch_pair<32, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else if (n <= 48)  launch_pair<48, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else if (n <= 64)  launch_pair<64, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else if (n <= 80)  launch_pair<80, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else if (n <= 96)  launch_pair<96, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else if (n <= 112) launch_pair<112, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else               launch_pair<128, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    if (n <= 8)        return launch_pair<8, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else if (n <= 16)  return launch_pair<16, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else if (n <= 24)  return launch_pair<24, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else if (n <= 32)  return launch_pair<32, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else if (n <= 48)  return launch_pair<48, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else if (n <= 64)  return launch_pair<64, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else if (n <= 80)  return launch_pair<80, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else if (n <= 96)  return launch_pair<96, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else if (n <= 112) return launch_pair<112, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    else               return launch_pair<128, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
 }
 
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
                                    const char **name, hipEvent_t dominant_done,
                                    bool winsor, AfterDominant after, void *user)
 {
-    if (winsor) launch_sized<true>(args, fargs, stream, name, dominant_done, after, user);
-    else        launch_sized<false>(args, fargs, stream, name, dominant_done, after, user);
-    return hipGetLastError();
+    hipError_t err = winsor ? launch_sized<true>(args, fargs, stream, name, dominant_done, after, user)
+                            : launch_sized<false>(args, fargs, stream, name, dominant_done, after, user);
+    keep_first(err, hipGetLastError());
+    return err;
 }
 
 }  // namespace nl

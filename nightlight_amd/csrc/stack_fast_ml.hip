@@ -592,10 +592,14 @@ int fast_ml_supported(int mode, bool weighted, int n_frames, int64_t npix)
     return ((mode == NL_ST_SIGMA || mode == NL_ST_WINSOR_SIGMA) && !weighted) ? 1 : 0;
 }
 
+// the nested launchers end in hipGetLastError(), which clears the pending error: keep the first one
+static inline void keep_first(hipError_t &acc, hipError_t e) { if (acc == hipSuccess) acc = e; }
+
 template <int LPP, bool WINSOR, bool WIDE>
-static void launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
-                      hipEvent_t dominant_done, AfterDominant after, void *user, const char **mlz_name)
+static hipError_t launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
+                            hipEvent_t dominant_done, AfterDominant after, void *user, const char **mlz_name)
 {
+    hipError_t err = hipSuccess;
     const unsigned per_wg = 256 / LPP;
     const unsigned tile_blocks = (unsigned)((args.npix + per_wg - 1) / per_wg);
     FastArgs f = fargs;
@@ -604,12 +608,13 @@ static void launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t 
     f.in_capacity = 0;
     if (!WIDE && mlz_name) {
         // every position in use: the clipping rounds run on LDS columns (stack_fast_mlz.hip)
-        (void)launch_stack_sigma_mlz(args, f, stream, mlz_name, WINSOR);
+        keep_first(err, launch_stack_sigma_mlz(args, f, stream, mlz_name, WINSOR));
     } else {
         hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, true, WINSOR, WIDE>), dim3(tile_blocks), dim3(256), 0, stream,
                            args, f);
+        keep_first(err, hipGetLastError());
     }
-    if (dominant_done) (void)hipEventRecord(dominant_done, stream);
+    if (dominant_done) keep_first(err, hipEventRecord(dominant_done, stream));
     if (after) after(user);
     f.in_list = fargs.gen_list;
     f.in_count = fargs.gen_count;
@@ -618,16 +623,18 @@ static void launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t 
     // switch) keeps the register version, which masks every position of every lane in every round
     static const bool mlg_on = [] { const char *e = getenv("NL_MLG"); return !(e && e[0] == '0'); }();
     if (mlg_on) {
-        (void)launch_stack_sigma_mlg(args, f, 4 * kGenericGrid, stream, WINSOR);
-        return;
+        keep_first(err, launch_stack_sigma_mlg(args, f, 4 * kGenericGrid, stream, WINSOR));
+        return err;
     }
     const unsigned gblocks = tile_blocks < kGenericGrid ? tile_blocks : kGenericGrid;
     hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, false, WINSOR, false>), dim3(gblocks), dim3(256), 0, stream,
                        args, f);
+    keep_first(err, hipGetLastError());
+    return err;
 }
 
 template <int LPP>
-static void launch_ml_variant(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name,
+static hipError_t launch_ml_variant(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name,
                               hipEvent_t dominant_done, bool winsor, AfterDominant after, void *user)
 {
     // tight zones when (almost) every position is used, otherwise the wide variant while the
@@ -645,17 +652,15 @@ static void launch_ml_variant(const StackArgs &args, const FastArgs &fargs, hipS
     static const bool mlz_on = [] { const char *e = getenv("NL_MLZ"); return !(e && e[0] == '0'); }();
     const char **mlz_name = (mlz_on && fast_mlz_supported(winsor ? NL_ST_WINSOR_SIGMA : NL_ST_SIGMA, false, n)) ? name : nullptr;
     if (mlz_name) {            // every frame count 129..512: LDS-column kernel of its class (stack_fast_mlz.hip)
-        if (winsor) launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user, mlz_name);
-        else        launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user, mlz_name);
-        return;
+        if (winsor) return launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user, mlz_name);
+        return launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user, mlz_name);
     }
     if (winsor) {
-        if (wide) launch_ml<LPP, true, true>(args, fargs, stream, dominant_done, after, user, nullptr);
-        else      launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user, nullptr);
-    } else {
-        if (wide) launch_ml<LPP, false, true>(args, fargs, stream, dominant_done, after, user, nullptr);
-        else      launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user, nullptr);
+        if (wide) return launch_ml<LPP, true, true>(args, fargs, stream, dominant_done, after, user, nullptr);
+        return launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user, nullptr);
     }
+    if (wide) return launch_ml<LPP, false, true>(args, fargs, stream, dominant_done, after, user, nullptr);
+    return launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user, nullptr);
 }
 
 // kernel names as rocprofv3 prints them (template arguments: LPP, ZONAL, WINSOR, WIDE)
@@ -663,9 +668,11 @@ hipError_t launch_stack_sigma_ml(const StackArgs &args, const FastArgs &fargs, h
                                  const char **name, hipEvent_t dominant_done, bool winsor,
                                  AfterDominant after, void *user)
 {
-    if (args.n_frames <= 2 * kMlNS) launch_ml_variant<2>(args, fargs, stream, name, dominant_done, winsor, after, user);
-    else                            launch_ml_variant<4>(args, fargs, stream, name, dominant_done, winsor, after, user);
-    return hipGetLastError();
+    hipError_t err = args.n_frames <= 2 * kMlNS
+        ? launch_ml_variant<2>(args, fargs, stream, name, dominant_done, winsor, after, user)
+        : launch_ml_variant<4>(args, fargs, stream, name, dominant_done, winsor, after, user);
+    keep_first(err, hipGetLastError());
+    return err;
 }
 
 }  // namespace nl

@@ -50,6 +50,9 @@ struct FastArgs {
     unsigned in_capacity;
 };
 
+// sets what nl_last_error() returns on this thread (nlstack_api.hip)
+void set_last_error(const char *msg);
+
 // Bisection of the goal-seek (spec: internal/ops/stack/stackfindsigma.go:48-98): sigma_low and
 // sigma_high in [1,11], percentages in the reference's fp32 arithmetic, 21 passes at most.
 // Host arithmetic shared by nl_stack_find_sigmas and nl_group_find_sigmas.

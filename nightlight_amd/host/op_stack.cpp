@@ -291,6 +291,9 @@ Result OpStack::Apply(const std::vector<ImagePtr> &f, Context *c)
         int rc = Resident ? nl_group_set_active_frames(h, (int)f.size()) : NL_OK;
         for (size_t i = 0; i < f.size() && rc == NL_OK; i++) {
             if (f[i]->Data.size() != f[0]->Data.size()) { out.err = "frames differ in size"; break; }
+            // a resident group was sized by an earlier batch: a frame of another size would be read
+            // past its end by the per-tile row copies
+            if (Resident && (int64_t)f[i]->Data.size() != ResidentPixels) { out.err = "frames differ in size"; break; }
             rc = nl_group_upload_frame(h, (int)i, f[i]->Data.data());       // overlapped; pointer not retained
         }
         if (!out.err.empty()) break;
@@ -378,7 +381,13 @@ bool OpStackBatches::partition(const std::vector<Promise> &ins, Context *c, std:
     snprintf(line, sizeof line, "\nEstimating memory needs for %lld images from %s:\n", (long long)numFrames,
              first.image->FileName.c_str());
     if (c->Log) *c->Log << line;
+    if (first.image->Naxisn.size() < 2 || first.image->Naxisn[0] <= 0 || first.image->Naxisn[1] <= 0 ||
+        (int64_t)first.image->Naxisn[0] * first.image->Naxisn[1] != (int64_t)first.image->Data.size()) {
+        *err = "No input files to prepare batches";          // a frame without a 2-D shape cannot size the batches
+        return false;
+    }
     const int64_t width = first.image->Naxisn[0], height = first.image->Naxisn[1];
+    FirstWidth = (int)width; FirstHeight = (int)height;
     const int64_t pixels = width * height;
     const float mPixels = (float)width * (float)height * 1e-6f;
     const int64_t bytes = pixels * 4;
@@ -455,17 +464,15 @@ Result OpStackBatches::Apply(const std::vector<Promise> &ins, Context *c)
     nl_group_t *resident = nullptr;
     struct Guard {
         nl_group_t **g; std::shared_ptr<OpStack> per;
-        ~Guard() { if (per) per->Resident = nullptr; if (*g) nl_group_destroy(*g); }
+        ~Guard() { if (per) { per->Resident = nullptr; per->ResidentPixels = 0; } if (*g) nl_group_destroy(*g); }
     } guard{&resident, PerBatch};
     if (numBatches > 1 && PerBatch) {
-        Result first = insPerm[0]();
-        if (!first.err.empty() || !first.image) return {nullptr, first.err.empty() ? "No input files to prepare batches" : first.err};
-        const int width = first.image->Naxisn[0];
-        const int height = (int)(first.image->Data.size() / (size_t)width);
+        // sized by the frame partition() already loaded (the promise is not run a second time)
         const std::vector<int> devs = devices_for(c);
-        resident = nl_group_create((int)batchSize, width, height, (int)devs.size(), devs.data());
+        resident = nl_group_create((int)batchSize, FirstWidth, FirstHeight, (int)devs.size(), devs.data());
         if (!resident) return {nullptr, nl_last_error()};
         PerBatch->Resident = resident;
+        PerBatch->ResidentPixels = (int64_t)FirstWidth * FirstHeight;
     }
 
     ImagePtr stack;

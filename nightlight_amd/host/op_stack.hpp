@@ -22,6 +22,7 @@ struct OpStack : Operator, OpBase {
     // (OpStackBatches).  When set, Apply stacks on it and leaves the result tile on the devices
     // (the returned image carries metadata only) for nl_group_accumulate.
     ::nl_group *Resident = nullptr;
+    int64_t ResidentPixels = 0;           // width*height the resident group was created for (every frame must match)
 
     std::string GetType() const override { return Type; }
     // stack.go:102-111: N inputs -> exactly one output promise
@@ -46,6 +47,7 @@ void RegisterOpStack();
 struct OpStackBatches : Operator, OpBase {
     std::shared_ptr<OpStack> PerBatch;    // json:"perBatch"
     std::vector<int> LastPerm;            // not in the reference: input index of every position after partition()
+    int FirstWidth = 0, FirstHeight = 0;  // size of the frame partition() looked at (stackbatches.go:130-141); sizes the device group
 
     std::string GetType() const override { return Type; }
     std::vector<Promise> MakePromises(const std::vector<Promise> &ins, Context *c,

@@ -25,10 +25,21 @@ class StackHandle:
         if not self._h:
             raise capi.NlError(capi.ERR_HIP, capi.last_error())
 
+    @classmethod
+    def _borrow(cls, handle, n_frames, width, height, row0, rows):
+        """View of a handle owned by someone else (a tile of an nl_group): never destroyed here."""
+        self = cls.__new__(cls)
+        self._lib = capi.load()
+        self.n_frames, self.width, self.height = int(n_frames), int(width), int(height)
+        self.row0, self.rows, self.device = int(row0), int(rows), -1
+        self._h, self._borrowed = handle, True
+        return self
+
     # -- lifecycle ---------------------------------------------------------
     def close(self):
         if self._h:
-            self._lib.nl_stack_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._lib.nl_stack_destroy(self._h)
             self._h = None
 
     def __enter__(self):
@@ -305,6 +316,14 @@ class StackGroup:
         r0, nr = C.c_int(), C.c_int()
         self._lib.nl_group_tile_rows(self.height, self.size, int(t), C.byref(r0), C.byref(nr))
         return r0.value, nr.value
+
+    def tile(self, t):
+        """Borrowed view of tile t's handle (nl_group_tile): the group keeps ownership."""
+        r0, nr = self.tile_rows(t)
+        h = self._lib.nl_group_tile(self._g, int(t))
+        if not h:
+            raise IndexError(t)
+        return StackHandle._borrow(h, self.n_frames, self.width, self.height, r0, nr)
 
     def upload_frames(self, frames):
         for i, f in enumerate(frames):

@@ -152,3 +152,114 @@ def test_tile_beyond_32bit_offsets_takes_the_int64_kernels(nl, oracle):
             frames = np.stack([st.download_rows(k, r, 2) for k in range(n)])
             rc, want, _, _, _ = oracle.stack_apply(2, frames, None, 1.5, 1.5, 0.0, num_cpu=8)
             assert bits_equal(st.download_rows(-1, r, 2), want), "rows %d.." % r
+
+
+def _bisection(run_pass, total, perc_lo, perc_hi):
+    """binarySearchAndStack (internal/ops/stack/stackfindsigma.go:48-98) restated on the test side
+    in fp32; run_pass(sigma_low, sigma_high) -> (clip_low, clip_high).  Returns the trajectory."""
+    F = np.float32
+    lo_l, lo_r, hi_l, hi_r = F(1), F(11), F(1), F(11)
+    lo_m, hi_m = F(0.5) * (lo_l + lo_r), F(0.5) * (hi_l + hi_r)
+    steps = []
+    i = 0
+    while True:
+        cl, ch = run_pass(float(lo_m), float(hi_m))
+        steps.append((float(lo_m), float(hi_m), cl, ch))
+        pl = F(cl) * F(100) / F(total)
+        ph = F(ch) * F(100) / F(total)
+        dl = int(F(100) * pl + F(0.5)) - int(F(100) * F(perc_lo))
+        dh = int(F(100) * ph + F(0.5)) - int(F(100) * F(perc_hi))
+        if (dl == 0 and dh == 0) or i >= 20:
+            return steps
+        if dl > 0:
+            lo_l = lo_m
+        elif dl < 0:
+            lo_r = lo_m
+        lo_m = F(0.5) * (lo_l + lo_r)
+        if dh > 0:
+            hi_l = hi_m
+        elif dh < 0:
+            hi_r = hi_m
+        hi_m = F(0.5) * (hi_l + hi_r)
+        i += 1
+
+
+def test_c3_as_stated_winsor_goal_seek_512x4096x4096_over_8_tiles(nl, oracle):
+    """BASELINE.json configs[2] in its stated form: 512 frames of 4096x4096, winsorized sigma
+    clipping with the goal-seek on the clip percentages (stackfindsigma.go:48-98, targets 0.5 % /
+    0.5 %, README.md:155-156), the image split into 8 row tiles whose counters are summed after
+    every pass (stack.go:142-152, 193-198).  One device holds all 8 tiles (8 x 4 GiB) -- the same
+    nl_group_* code that puts tile t on GPU t.  Checked:
+    (1) the group's goal-seek = the reference's bisection (restated above) driven by the summed
+        per-tile counters of every pass: same number of passes, same sigmas, same counters;
+    (2) per pass, the group's counters = the sum over 8 FRESH single-tile handles (first and last pass);
+    (3) per pass of the trajectory, the counters of two 2-row strips = the oracle's on the same pixels;
+    (4) the result at the converged sigmas = the oracle on sampled row blocks, within 1e-5."""
+    n, width, height, tiles, mode = 512, 4096, 4096, 8, 3
+    total = n * width * height
+    rng = np.random.default_rng(33)
+    with nl.StackGroup(n, width, height, devices=[0] * tiles) as g:
+        assert g.size == tiles and [g.tile_rows(t) for t in range(tiles)] == [(512 * t, 512) for t in range(tiles)]
+        g.fill_synthetic(SEED)
+        result, cl, ch, sl, sh, passes = g.find_sigmas(mode, 0.5, 0.5)
+        views = [g.tile(t) for t in range(tiles)]
+        assert all(v.last_kernel_name.startswith("stack_sigma_mlz_kernel<4") for v in views), views[0].last_kernel_name
+
+        # (1) replay the bisection on the per-tile counters of the same tiles
+        def group_pass(sig_lo, sig_hi):
+            for v in views:
+                v.run_async(mode, sig_lo, sig_hi, 0.0)
+            per_tile = [v.finish() for v in views]
+            return sum(c[0] for c in per_tile), sum(c[1] for c in per_tile)
+        steps = _bisection(group_pass, total, 0.5, 0.5)
+        assert len(steps) == passes, (len(steps), passes)
+        assert steps[-1] == (sl, sh, cl, ch), (steps[-1], (sl, sh, cl, ch))
+        assert 2 <= passes <= 21
+        # the goal was met: both percentages round to 0.50 (stackfindsigma.go:64-70)
+        if passes <= 20:
+            assert int(np.float32(100) * (np.float32(cl) * np.float32(100) / np.float32(total)) + np.float32(0.5)) == 50
+            assert int(np.float32(100) * (np.float32(ch) * np.float32(100) / np.float32(total)) + np.float32(0.5)) == 50
+
+        # (4) oracle values at the converged sigmas on sampled row blocks (tile seams included)
+        block_rows = 2
+        starts = sorted(set([0, 510, 512, height - block_rows] +
+                            [int(r) for r in rng.integers(0, height - block_rows + 1, 4)]))
+        worst = 0.0
+        for r in starts:
+            t = r // 512
+            frames = np.stack([views[t].download_rows(k, r - 512 * t, block_rows) for k in range(n)])
+            rc, want, _, _, _ = oracle.stack_apply(mode, frames, None, sl, sh, 0.0, num_cpu=64)
+            assert rc == 0
+            got = result[r * width:(r + block_rows) * width]
+            assert np.array_equal(np.isnan(got), np.isnan(want)), "rows %d..: NaN pattern differs" % r
+            worst = max(worst, rel_err(got, want))
+        assert worst <= RTOL, "max relative difference %g" % worst
+        strip_frames = {}
+        for r in (0, 2046):                   # NaN-border rows of tile 0, interior rows at a tile seam
+            t = r // 512
+            strip_frames[r] = np.stack([views[t].download_rows(k, r - 512 * t, 2) for k in range(n)])
+
+    # (2) fresh single-tile handles: first and last pass of the trajectory
+    for (s_lo, s_hi, want_cl, want_ch) in (steps[0], steps[-1]):
+        sum_cl = sum_ch = 0
+        for t in range(tiles):
+            with nl.StackHandle(n, width, height, row0=512 * t, rows=512) as st:
+                st.fill_synthetic(SEED)
+                st.run_async(mode, s_lo, s_hi, 0.0)
+                c = st.finish()
+                if (s_lo, s_hi) == (sl, sh):
+                    assert bits_equal(st.download_rows(-1, 0, 512), result[512 * t * width:512 * (t + 1) * width])
+            sum_cl += c[0]
+            sum_ch += c[1]
+        assert (sum_cl, sum_ch) == (want_cl, want_ch), ((sum_cl, sum_ch), (want_cl, want_ch))
+
+    # (3) every pass of the trajectory: strip counters against the oracle
+    for r, frames in strip_frames.items():
+        with nl.StackHandle(n, width, height, row0=r, rows=2) as st:
+            st.fill_synthetic(SEED)
+            assert bits_equal(st.download_tile(7), frames[7])
+            for (s_lo, s_hi, _, _) in steps:
+                st.run_async(mode, s_lo, s_hi, 0.0)
+                c = st.finish()
+                rc, _, wl, wh, _ = oracle.stack_apply(mode, frames, None, s_lo, s_hi, 0.0, num_cpu=64)
+                assert rc == 0 and c == (wl, wh), "rows %d.. at sigmas %r: %r vs oracle %r" % (r, (s_lo, s_hi), c, (wl, wh))

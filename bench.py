@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=0,
                     help="rows of the stack timed on the CPU (0 = auto, about 3 s per run)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-also", action="store_true",
+                    help="default workload only: skip the 32- and 512-frame stacks reported under \"also\"")
     ap.add_argument("--weighted", action="store_true",
                     help="per-frame weights in [0.2, 1] (the shape of inverse-noise weights, stack.go:246-253)")
     ap.add_argument("--backend", default="nccl",
@@ -187,65 +189,86 @@ def main():
     else:
         image_rows = args.height
         row0, rows = tile_rows(image_rows, world, rank)
-    st = StackHandle(n, w, image_rows, row0=row0, rows=rows, device=device)
-    st.fill_synthetic()
-    weights = None
-    if args.weighted:
-        weights = np.array([0.2 + 0.8 * ((k * 37) % 101) / 100.0 for k in range(n)], np.float32)
-        st.set_weights(weights)
 
     # global clip totals (the log line of stack.go:214-218 needs them on every pass)
     totals = torch.zeros(2, dtype=torch.int64, device="cuda" if on_device else "cpu")
-    stream = torch.cuda.ExternalStream(st.stream_ptr, device=device) if (dist is not None and on_device) else None
-    pending = [None]
 
-    def step():
-        st.run_async(args.mode, args.kappa, args.kappa, 0.0)
-        if dist is None:
-            return
-        if on_device:
-            # device-side reduction on the handle's own stream; the all-reduce of pass i overlaps pass i+1
-            with torch.cuda.stream(stream):
-                if pending[0] is not None:
+    def time_stack(frames, mode, steps, warmup, weights=None):
+        """One workload on this rank's row tile: `warmup` untimed passes, then exactly `steps` timed ones
+        bracketed by barrier + synchronize.  Returns the handle (still open) and the timings."""
+        st = StackHandle(frames, w, image_rows, row0=row0, rows=rows, device=device)
+        st.fill_synthetic()
+        if os.environ.get("NL_DEV_FLAGS"):
+            st.set_dev_flags(int(os.environ["NL_DEV_FLAGS"]))
+        if weights is not None:
+            st.set_weights(weights)
+        stream = torch.cuda.ExternalStream(st.stream_ptr, device=device) if (dist is not None and on_device) else None
+        pending = [None]
+
+        def step():
+            st.run_async(mode, args.kappa, args.kappa, 0.0)
+            if dist is None:
+                return
+            if on_device:
+                # device-side reduction on the handle's own stream; the all-reduce of pass i overlaps pass i+1
+                with torch.cuda.stream(stream):
+                    if pending[0] is not None:
+                        pending[0].wait()
+                    st.copy_counters_async(totals.data_ptr())
+                    pending[0] = dist.all_reduce(totals, async_op=True)
+            else:                                   # gloo rehearsal: counters through the host
+                cl, ch = st.finish()
+                totals.copy_(torch.tensor([cl, ch], dtype=torch.int64))
+                dist.all_reduce(totals)
+
+        def fence():
+            if pending[0] is not None:
+                with torch.cuda.stream(stream):
                     pending[0].wait()
-                st.copy_counters_async(totals.data_ptr())
-                pending[0] = dist.all_reduce(totals, async_op=True)
-        else:                                   # gloo rehearsal: counters through the host
-            cl, ch = st.finish()
-            totals.copy_(torch.tensor([cl, ch], dtype=torch.int64))
-            dist.all_reduce(totals)
-
-    def fence():
-        if pending[0] is not None:
-            with torch.cuda.stream(stream):
-                pending[0].wait()
-            pending[0] = None
-        st.finish()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+                pending[0] = None
+            st.finish()
             torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+                torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
 
-    # HIP-event times of the timed passes, read back from the handle's ring after the fact
-    timed = min(args.steps, 64)
-    times = [st.pass_times(b) for b in range(timed)]
-    pass_ms = float(np.mean([t[0] for t in times]))
-    k_ms = float(np.mean([t[1] for t in times]))
-    cl, ch = st.finish()
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_device else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        cl, ch = int(totals[0].item()), int(totals[1].item())
+        # HIP-event times of the timed passes, read back from the handle's ring after the fact
+        timed = min(steps, 64)
+        times = [st.pass_times(b) for b in range(timed)]
+        pass_ms = float(np.mean([t[0] for t in times]))
+        k_ms = float(np.mean([t[1] for t in times]))
+        # one more pass, synchronous as OpStack.Apply runs it (enqueue, wait, read the counters back)
+        t1 = time.perf_counter()
+        st.run_async(mode, args.kappa, args.kappa, 0.0)
+        cl, ch = st.finish()
+        sync_ms = (time.perf_counter() - t1) * 1e3
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_device else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            if on_device:
+                st.copy_counters_async(totals.data_ptr())
+                torch.cuda.synchronize()
+            else:
+                totals.copy_(torch.tensor([cl, ch], dtype=torch.int64))
+            dist.all_reduce(totals)
+            cl, ch = int(totals[0].item()), int(totals[1].item())
+        return st, {"dt": dt, "pass_ms": pass_ms, "k_ms": k_ms, "timed": timed, "cl": cl, "ch": ch, "sync_ms": sync_ms}
+
+    weights = None
+    if args.weighted:
+        weights = np.array([0.2 + 0.8 * ((k * 37) % 101) / 100.0 for k in range(n)], np.float32)
+    st, tm = time_stack(n, args.mode, args.steps, args.warmup, weights)
+    dt, pass_ms, k_ms, timed, cl, ch = tm["dt"], tm["pass_ms"], tm["k_ms"], tm["timed"], tm["cl"], tm["ch"]
 
     if rank == 0:
         pixels_per_step = image_rows * w
@@ -283,6 +306,9 @@ def main():
                          "pass_ms": round(pass_ms, 4),
                          "pass_frac": round(alg_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          "pixels_redone_by_exact_kernel": st.last_fallback_pixels},
+            # ms_per_step times passes queued back to back (one host sync at the end of the timed region);
+            # this is one pass run the way OpStack.Apply runs it: enqueue, wait, read the counters back
+            "ms_per_step_synchronous": round(tm["sync_ms"], 4),
         }
         if world == 1 and not args.no_cpu:
             cpu_rows = args.cpu_rows
@@ -312,9 +338,34 @@ def main():
                 "within_1e-5": bool(same_nan and rel <= 1e-5),
             }
             out["cpu_baseline"] = base
-        print(json.dumps(out), flush=True)
 
     st.close()
+    # The other stack depths the north star names (4096 x 4096 x {32, 512} fp32, sigma clipping), same protocol
+    # and the same row tiles, reported beside the headline (which stays what `value` is).
+    default_workload = (args.frames == 128 and args.mode == 2 and args.width == 4096 and args.height == 4096 and
+                        not args.weak and not args.weighted and not args.image_height)
+    if default_workload and not args.no_also:
+        also = []
+        for frames in (32, 512):
+            st2, t2 = time_stack(frames, 2, args.steps, args.warmup)
+            if rank == 0:
+                alg = 4.0 * rows * w * (frames + 1)
+                also.append({
+                    "workload": "%d x %dx%d fp32 frames, sigma-clip kappa=%g, rows split over %d GPU(s)" % (
+                        frames, image_rows, w, args.kappa, world),
+                    "value": round(image_rows * w * args.steps / t2["dt"] / 1e6, 3), "unit": "Mpixels/s",
+                    "ms_per_step": round(t2["dt"] * 1e3 / args.steps, 4),
+                    "ms_per_step_synchronous": round(t2["sync_ms"], 4),
+                    "kernel": st2.last_kernel_name, "kernel_ms": round(t2["k_ms"], 4), "pass_ms": round(t2["pass_ms"], 4),
+                    "frac": round(alg / (t2["k_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "pass_frac": round(alg / (t2["pass_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "algorithmic_bytes": alg, "clip_low": t2["cl"], "clip_high": t2["ch"],
+                    "pixels_redone_by_exact_kernel": st2.last_fallback_pixels})
+            st2.close()
+        if rank == 0:
+            out["also"] = also
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -166,6 +166,12 @@ int nl_stack_copy_counters_async(nl_stack_t *h, void *device_dst);
  * counters identical to the reference's and the output within summation-order
  * rounding, and hands undecidable pixels to the exact kernel. */
 int nl_stack_set_exact(nl_stack_t *h, int on);
+/* Developer switches of the sigma / winsorized fast path, for A/B timing inside one process (results are the
+ * same either way): bit 0 = plain pass protocol (memset before, reduction kernel after every pass) instead of
+ * the fused one, bit 1 = the exact replay of the dominant kernel's hand-overs runs in front of the generic pass
+ * on the same stream instead of beside it (kernel traces then show each kernel's own duration).  Default 0.
+ * No counterpart in the reference. */
+int nl_stack_set_dev_flags(nl_stack_t *h, unsigned flags);
 /* Pixels of the last pass that were re-done by the exact kernel. */
 int64_t nl_stack_last_fallback_pixels(nl_stack_t *h);
 /* Pixels of the last pass that the dominant kernel handed to the generic pass (all positions

@@ -41,7 +41,7 @@ EXPORTS = [
     "nl_group_upload_frame", "nl_group_fill_synthetic", "nl_group_set_active_frames", "nl_group_set_weights", "nl_group_set_exact",
     "nl_group_run", "nl_group_last_mode", "nl_group_find_sigmas", "nl_group_accumulate",
     "nl_group_accumulate_finalize",
-    "nl_stack_set_exact", "nl_stack_last_fallback_pixels", "nl_stack_last_generic_pixels",
+    "nl_stack_set_exact", "nl_stack_set_dev_flags", "nl_stack_last_fallback_pixels", "nl_stack_last_generic_pixels",
     "nl_stack_find_sigmas", "nl_stack_accumulate", "nl_stack_accumulate_finalize",
     "nl_stack_frame_stats", "nl_stack_frame_noise", "nl_stack_weights_from_noise",
     "nl_median_filter_3x3", "nl_median_filter_mask",
@@ -113,6 +113,7 @@ def load():
     L.nl_stack_last_kernel_name.argtypes = [vp]
     L.nl_stack_last_kernel_name.restype = C.c_char_p
     L.nl_stack_set_exact.argtypes = [vp, C.c_int]
+    L.nl_stack_set_dev_flags.argtypes = [vp, C.c_uint]
     L.nl_stack_pass_times.argtypes = [vp, C.c_int, _f32p, _f32p]
     L.nl_stack_stream.argtypes = [vp]
     L.nl_stack_stream.restype = vp

@@ -34,6 +34,42 @@ __device__ __forceinline__ void snapshot_fb_list(const FastArgs &q)
     __syncthreads();
 }
 
+// ---- fused pass protocol (StackArgs::final, see stack_kernels.h and nlstack_api.hip) ----
+// dominant kernel, first workgroup: zero this pass's totals and the scratch set of the NEXT pass (everything
+// that used either is stream-ordered before this kernel)
+__device__ __forceinline__ void fused_prologue_dominant(const StackArgs &p)
+{
+    if (p.zero_next && blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < kScratchWords; i += blockDim.x) p.zero_next[i] = 0ull;
+        if (threadIdx.x < 4) p.final[threadIdx.x] = 0ull;
+    }
+}
+// generic pass, first wave of the first workgroup: the dominant kernel's sharded counts -> totals
+__device__ __forceinline__ void fused_collect_slots(const StackArgs &p)
+{
+    if (p.final && blockIdx.x == 0 && threadIdx.x < 64) {
+        unsigned long long lo = 0, hi = 0;
+        for (int i = threadIdx.x; i < kClipSlots; i += 64) {
+            lo += p.partial[2 * (size_t)i];
+            hi += p.partial[2 * (size_t)i + 1];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo += ((unsigned long long)(unsigned)__shfl_xor((int)(lo >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)lo, o, 64);
+            hi += ((unsigned long long)(unsigned)__shfl_xor((int)(hi >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)hi, o, 64);
+        }
+        if (threadIdx.x == 0) {
+            if (lo) atomicAdd(p.final + 0, lo);
+            if (hi) atomicAdd(p.final + 1, hi);
+        }
+    }
+}
+// where a kernel that runs AFTER the dominant one adds its clip counts: the totals, or (plain protocol) a shard
+__device__ __forceinline__ unsigned long long *clip_slot(const StackArgs &p)
+{
+    return p.final ? p.final : p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+}
+
 // compile-time loops: every index is a constant, so register columns never
 // fall back to scratch memory (pragma unroll gives up on the large networks)
 template <int B, int... I, class F>

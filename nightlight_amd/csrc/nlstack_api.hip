@@ -52,8 +52,10 @@ constexpr int kStatBlocks = 2048;
 constexpr int kListGrid = 2048;     // workgroups of the exact kernel in fallback-list mode
 constexpr int kCoopGrid = 16384;    // workgroups (one wave each) of the wave-per-pixel exact replay
 constexpr int kListLanes = 4;       // pixels per wave there: few pixels, keep divergence low
-// per-pass device scratch, zeroed by one memset: clip accumulators + the two list lengths
-constexpr size_t kScratchBytes = sizeof(unsigned long long) * (2 * nl::kClipSlots + 2);   // + list lengths + snapshot
+constexpr unsigned kFusedMaxList = 512;    // exact-list length up to which a pass runs the fused protocol
+// per-pass device scratch, zeroed by one memset (or, in the fused protocol of the sigma / winsorized fast path, by
+// the previous pass's dominant kernel -- two sets alternate): clip accumulators + list lengths + snapshot
+constexpr size_t kScratchBytes = sizeof(unsigned long long) * nl::kScratchWords;
 
 int next_pow2(int n)
 {
@@ -87,7 +89,14 @@ struct nl_stack {
     float *d_weights = nullptr;       // [n_frames]
     bool has_weights = false;
     float *d_xstat = nullptr;         // [(n_frames+1)*2]
-    unsigned long long *d_partial = nullptr;   // [kClipSlots][2] clip accumulators + 1 word of list lengths
+    unsigned long long *d_sets = nullptr;      // two scratch sets of kScratchWords; d_partial = the current one
+    int cur_set = 0;
+    bool sets_clean = false;                   // both sets as a fused pass leaves them: the current one used, the other zeroed
+    unsigned long long *d_partial = nullptr;   // [kClipSlots][2] clip accumulators + 2 words of list lengths
+    unsigned fb_hint = 0;                      // exact-list length of the last finished fast pass + 1 (0 = unknown)
+    bool last_fused = false;
+    bool last_lists = false;                   // the last pass left its list lengths behind the totals (d_counters[2])
+    unsigned dev_flags = 0;                    // nl_stack_set_dev_flags (A/B measurements)
     unsigned *d_fb_list = nullptr;             // [npix] pixels the fast kernel handed to the exact kernel
     unsigned *d_fb_count = nullptr;            // [2]: exact-list length, generic-list length (inside d_partial)
     unsigned *d_gen_list = nullptr;            // [npix] pixels zonal waves handed to the generic pass
@@ -145,7 +154,7 @@ static int destroy_impl(nl_stack_t *h)
     if (h->d_acc) (void)hipFree(h->d_acc);
     if (h->d_weights) (void)hipFree(h->d_weights);
     if (h->d_xstat) (void)hipFree(h->d_xstat);
-    if (h->d_partial) (void)hipFree(h->d_partial);
+    if (h->d_sets) (void)hipFree(h->d_sets);
     if (h->d_fb_list) (void)hipFree(h->d_fb_list);
     if (h->d_gen_list) (void)hipFree(h->d_gen_list);
     if (h->d_counters) (void)hipFree(h->d_counters);
@@ -207,15 +216,17 @@ static int create_impl(nl_stack_t *h)
     NL_HIP(hipMalloc(&h->d_out, frame_bytes));
     NL_HIP(hipMalloc(&h->d_weights, sizeof(float) * (size_t)h->n_frames));
     h->max_grid = 256 * 64;
-    NL_HIP(hipMalloc(&h->d_partial, kScratchBytes));
-    NL_HIP(hipMemsetAsync(h->d_partial, 0, kScratchBytes, h->stream));
+    NL_HIP(hipMalloc(&h->d_sets, 2 * kScratchBytes));
+    NL_HIP(hipMemsetAsync(h->d_sets, 0, 2 * kScratchBytes, h->stream));
+    h->cur_set = 0;
+    h->d_partial = h->d_sets;
     h->d_fb_count = reinterpret_cast<unsigned *>(h->d_partial + 2 * nl::kClipSlots);
     if (h->npix < (int64_t)0xFFFFFFFFll) {
         NL_HIP(hipMalloc(&h->d_fb_list, sizeof(unsigned) * (size_t)h->npix));
         NL_HIP(hipMalloc(&h->d_gen_list, sizeof(unsigned) * (size_t)h->npix));
     }
-    NL_HIP(hipMalloc(&h->d_counters, sizeof(unsigned long long) * 2));
-    NL_HIP(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * 2, h->stream));
+    NL_HIP(hipMalloc(&h->d_counters, sizeof(unsigned long long) * 4));      // {clip_low, clip_high, list lengths (fused passes), -}
+    NL_HIP(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * 4, h->stream));
     NL_HIP(hipMalloc(&h->d_stat_partial, sizeof(double) * 3 * kStatBlocks));
 
     // stats.MeanStdDev over xs = 0..n-1 (stats.go:246-261, called from :570)
@@ -534,6 +545,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
     a.list_capacity = 0;
     a.list_snap = nullptr;
     a.list_part = 0;
+    a.final = nullptr;
+    a.zero_next = nullptr;
 
     {
         const int slot = (int)(h->pass_seq % kTimingRing);
@@ -541,7 +554,33 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         h->ev_dom0 = h->ring_dom0[slot]; h->ev_dom1 = h->ring_dom1[slot];
     }
     NL_HIP(hipEventRecord(h->ev_start, h->stream));
-    NL_HIP(hipMemsetAsync(h->d_partial, 0, kScratchBytes, h->stream));
+    // The sigma / winsorized fast path from 17 frames on (a zonal kernel followed by a generic pass) runs the
+    // FUSED protocol (StackArgs::final): no memset in front of the pass -- the previous fused pass's dominant
+    // kernel zeroed this pass's scratch set, the two sets alternate -- and no reduction kernel behind it.
+    // NL_FUSED=0 (developer switch) keeps memset + reduce_counters_kernel for A/B runs.
+    static const bool fused_on = [] {
+        for (const char *name : {"NL_FUSED", "NL_MLG", "NL_MLZ"}) { const char *e = getenv(name); if (e && e[0] == '0') return false; }
+        return true;
+    }();
+    const bool sigma_fast = !h->force_exact && h->d_fb_list && (mode == NL_ST_SIGMA || mode == NL_ST_WINSOR_SIGMA) &&
+                            (nl::fast_supported(mode, weighted, a.n_frames, a.npix) ||
+                             nl::fast_ml_supported(mode, weighted, a.n_frames, a.npix));
+    // (only while the exact list is short -- the length the last finished pass reported: its replays add their
+    // counts to ONE word, and thousands of workgroups doing that take longer than a reduction kernel)
+    const bool fused = fused_on && !(h->dev_flags & 1u) && sigma_fast && a.n_frames > 16 && h->fb_hint != 0 &&
+                       h->fb_hint - 1u < kFusedMaxList && nl::coop_supported(mode, weighted, a.n_frames) != 0;
+    if (fused) {
+        if (h->sets_clean) h->cur_set ^= 1;
+        else NL_HIP(hipMemsetAsync(h->d_sets, 0, 2 * kScratchBytes, h->stream));
+        h->d_partial = h->d_sets + (size_t)h->cur_set * nl::kScratchWords;
+        h->d_fb_count = reinterpret_cast<unsigned *>(h->d_partial + 2 * nl::kClipSlots);
+        a.partial = h->d_partial;
+        a.final = h->d_counters;
+        a.zero_next = h->d_sets + (size_t)(h->cur_set ^ 1) * nl::kScratchWords;
+    } else {
+        NL_HIP(hipMemsetAsync(h->d_partial, 0, kScratchBytes, h->stream));
+    }
+    h->sets_clean = false;                       // until this pass is enqueued completely
     NL_HIP(hipEventRecord(h->ev_dom0, h->stream));
     if (mode == NL_ST_MEAN) {
         NL_HIP(nl::launch_stack_mean(weighted, a, h->stream, &h->last_kernel));
@@ -651,6 +690,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
                (nl::fast_supported(mode, weighted, a.n_frames, a.npix) || nl::fast_ml_supported(mode, weighted, a.n_frames, a.npix))) {
         // register-resident fast kernel; pixels it cannot decide go to the exact kernel
         nl::FastArgs f;
+        memset(&f, 0, sizeof f);
         f.fb_list = h->d_fb_list;
         f.fb_count = h->d_fb_count;
         f.fb_capacity = (unsigned)h->npix;
@@ -671,18 +711,36 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         e.list_capacity = (unsigned)h->npix;
         const bool coop = nl::coop_supported(mode, weighted, a.n_frames) != 0;
         unsigned *snap = h->d_fb_count + 2;               // 1 + list length when the first replay started (set on the device)
-        struct Fork { nl_stack *h; nl::StackArgs e; int mode; unsigned *snap; hipError_t err; } fork{h, e, mode, snap, hipSuccess};
+        // replay grids: one wave per workgroup, grid-stride over a list whose length is only known on the device;
+        // launching 16 k workgroups for a few hundred pixels costs more than replaying them, so the length the
+        // last finished pass reported (nl_stack_finish) sizes the grid
+        int grid0 = kCoopGrid, grid1 = kCoopGrid / 4;
+        if (h->fb_hint) {
+            const int want = next_pow2((int)(2u * (h->fb_hint - 1u) + 64u));
+            grid0 = want < 1024 ? 1024 : (want > kCoopGrid ? kCoopGrid : want);
+            grid1 = grid0 / 4 < 512 ? 512 : grid0 / 4;
+        }
+        struct Fork { nl_stack *h; nl::StackArgs e; int mode; unsigned *snap; int grid0; hipError_t err; } fork{h, e, mode, snap, grid0, hipSuccess};
         nl::AfterDominant after = nullptr;
         if (coop) after = [](void *u) {
             Fork *k = static_cast<Fork *>(u);
             nl_stack *hh = k->h;
             const char *ignored = "";
             hipError_t err = hipEventRecord(hh->ev_fork, hh->stream);
+            if (hh->dev_flags & 2u) {            // developer switch: the first replay in front of the generic pass, same stream
+                nl::StackArgs first = k->e;
+                first.list_snap = k->snap;
+                first.list_part = 0;
+                if (err == hipSuccess) err = nl::launch_stack_sigma_coop(k->mode, first, k->grid0, hh->stream, &ignored);
+                if (err == hipSuccess) err = hipEventRecord(hh->ev_join, hh->stream);
+                k->err = err;
+                return;
+            }
             if (err == hipSuccess) err = hipStreamWaitEvent(hh->side_stream, hh->ev_fork, 0);
             nl::StackArgs first = k->e;
             first.list_snap = k->snap;                    // the list as the dominant kernel left it (snapshot on the device)
             first.list_part = 0;
-            if (err == hipSuccess) err = nl::launch_stack_sigma_coop(k->mode, first, kCoopGrid, hh->side_stream, &ignored);
+            if (err == hipSuccess) err = nl::launch_stack_sigma_coop(k->mode, first, k->grid0, hh->side_stream, &ignored);
             if (err == hipSuccess) err = hipEventRecord(hh->ev_join, hh->side_stream);
             k->err = err;
         };
@@ -697,7 +755,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         if (coop) {
             e.list_snap = snap;                           // the generic pass's additions
             e.list_part = 1;
-            NL_HIP(nl::launch_stack_sigma_coop(mode, e, kCoopGrid / 4, h->stream, &exact_name));
+            NL_HIP(nl::launch_stack_sigma_coop(mode, e, grid1, h->stream, &exact_name));
             NL_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         } else {
             int lanes = 0;
@@ -707,7 +765,10 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
                             "%d frames do not fit the per-pixel LDS column (mode %d)", a.n_frames, mode);
             NL_HIP(nl::launch_stack_exact(mode, weighted, e, lanes, kListGrid, lds, h->stream, &exact_name));
         }
-        NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
+        if (fused) h->sets_clean = true;             // (fused implies coop: every kernel of the pass is enqueued)
+        else NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream, h->d_fb_count));
+        h->last_lists = true;
+        h->last_fused = fused;
         h->last_has_counters = true;
         h->last_used_fast = true;
     } else if ((h->exact_flavour == 3 || (!h->force_exact && weighted && a.n_frames <= nl::kTileMaxFramesDefault)) &&
@@ -753,6 +814,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         h->last_has_counters = (mode != NL_ST_MEDIAN);
     }
     NL_HIP(hipEventRecord(h->ev_stop, h->stream));
+    if (!fused) h->last_fused = false;
+    if (!sigma_fast) h->last_lists = false;
     h->pass_seq++;
     h->last_mode = mode;
     h->pending = true;
@@ -762,14 +825,16 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
 int nl_stack_finish(nl_stack_t *h, float *out_host, int64_t *clip_low, int64_t *clip_high)
 {
     NL_CHECK_HANDLE(h);
-    unsigned long long c[2] = {0, 0};
-    if (h->last_has_counters && (clip_low || clip_high))
-        NL_HIP(hipMemcpyAsync(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    unsigned long long c[4] = {0, 0, 0, 0};
+    // (a fast sigma / winsorized pass leaves its list lengths behind the totals: c[2] = exact list | generic list << 32)
+    if (h->last_has_counters && (clip_low || clip_high || h->last_lists))
+        NL_HIP(hipMemcpyAsync(c, h->d_counters, h->last_lists ? 3 * sizeof c[0] : 2 * sizeof c[0], hipMemcpyDeviceToHost, h->stream));
     if (out_host)
         NL_HIP(hipMemcpyAsync(out_host + (int64_t)h->row0 * h->width, h->d_out,
                               (size_t)h->npix * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     NL_HIP(hipStreamSynchronize(h->stream));
     h->pending = false;
+    if (h->last_has_counters && h->last_lists) h->fb_hint = (unsigned)(c[2] & 0xffffffffull) + 1u;
     if (clip_low) *clip_low = (int64_t)c[0];
     if (clip_high) *clip_high = (int64_t)c[1];
     return NL_OK;
@@ -798,6 +863,13 @@ int nl_stack_set_exact(nl_stack_t *h, int on)
     NL_CHECK_HANDLE(h);
     h->force_exact = on != 0;
     h->exact_flavour = on;
+    return NL_OK;
+}
+
+int nl_stack_set_dev_flags(nl_stack_t *h, unsigned flags)
+{
+    NL_CHECK_HANDLE(h);
+    h->dev_flags = flags;
     return NL_OK;
 }
 

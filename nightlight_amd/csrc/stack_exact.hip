@@ -386,7 +386,8 @@ __global__ __launch_bounds__(64) void stack_exact_kernel(StackArgs p)
 
 __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned long long *partial,
                                                                int n_slots,
-                                                               unsigned long long *counters)
+                                                               unsigned long long *counters,
+                                                               const unsigned *list_counts)
 {
     __shared__ unsigned long long s_lo[256], s_hi[256];
     unsigned long long lo = 0, hi = 0;
@@ -407,6 +408,7 @@ __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned lon
     if (threadIdx.x == 0) {
         counters[0] = s_lo[0];
         counters[1] = s_hi[0];
+        if (list_counts) counters[2] = (unsigned long long)list_counts[0] | ((unsigned long long)list_counts[1] << 32);
     }
 }
 
@@ -488,10 +490,10 @@ hipError_t launch_stack_exact(int mode, bool weighted, StackArgs &args, int lane
 }
 
 hipError_t launch_reduce_counters(const unsigned long long *partial, int n_blocks,
-                                  unsigned long long *counters, hipStream_t stream)
+                                  unsigned long long *counters, hipStream_t stream, const unsigned *list_counts)
 {
     hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(256), 0, stream, partial, n_blocks,
-                       counters);
+                       counters, list_counts);
     return hipGetLastError();
 }
 

@@ -296,9 +296,14 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
         if (lane == 0) p.out[pix] = res;
     }
     if (lane == 0) {
-        unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+        // fused pass protocol (StackArgs::final): straight to the totals; the replay of the generic pass's
+        // additions is the last kernel of a pass and leaves the list lengths behind them ({exact | generic << 32}:
+        // the scratch layout of nlstack_api.hip) -- read back by nl_stack_finish with the totals
+        unsigned long long *slot = p.final ? p.final : p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
         if (c_lo) atomicAdd(slot + 0, (unsigned long long)c_lo);
         if (c_hi) atomicAdd(slot + 1, (unsigned long long)c_hi);
+        if (p.final && p.list && p.list_part == 1 && blockIdx.x == 0)
+            p.final[2] = (unsigned long long)p.list_count[0] | ((unsigned long long)p.list_count[1] << 32);
     }
 }
 

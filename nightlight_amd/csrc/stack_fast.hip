@@ -388,7 +388,8 @@ template <int NS, bool ZONAL, bool WINSOR, bool TIGHT>
 __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
 {
     static_assert(!TIGHT || ZONAL, "TIGHT is a variant of the zonal kernels");
-    if constexpr (!ZONAL) { if (q.in_list) snapshot_fb_list(q); }
+    if constexpr (ZONAL) fused_prologue_dominant(p);
+    if constexpr (!ZONAL) { if (q.in_list) { fused_collect_slots(p); snapshot_fb_list(q); } }
     // zone widths: 8 clipped + 8 missing samples per lane for the larger
     // networks, 4 + 4 for the small ones
     constexpr int KZ = NS >= 48 ? kZone : 4, KP = TIGHT ? 0 : (NS >= 48 ? kPadMax : 4);
@@ -798,6 +799,7 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         const int t_lo = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3];
         const int t_hi = s_hi[0] + s_hi[1] + s_hi[2] + s_hi[3];
         unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+        if constexpr (!ZONAL) slot = clip_slot(p);
         if (t_lo) atomicAdd(slot + 0, (unsigned long long)t_lo);
         if (t_hi) atomicAdd(slot + 1, (unsigned long long)t_hi);
     }

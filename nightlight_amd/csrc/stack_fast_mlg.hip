@@ -148,7 +148,7 @@ void stack_sigma_mlg_kernel(StackArgs p, FastArgs q)
     using LY = MlgLayout<LPP>;
     constexpr int NS = LY::NS, NT = LY::NT, PW = LY::PW;
     __shared__ float lds[LY::ROWS * PW];
-    if (q.in_list) snapshot_fb_list(q);
+    if (q.in_list) { fused_collect_slots(p); snapshot_fb_list(q); }
 
     const int lane = threadIdx.x & 63;
     const int role = threadIdx.x % LPP;
@@ -389,7 +389,7 @@ void stack_sigma_mlg_kernel(StackArgs p, FastArgs q)
         c_hi_total += __shfl_xor(c_hi_total, o, 64);
     }
     if (lane == 0) {
-        unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+        unsigned long long *slot = clip_slot(p);
         if (c_lo_total) atomicAdd(slot + 0, (unsigned long long)c_lo_total);
         if (c_hi_total) atomicAdd(slot + 1, (unsigned long long)c_hi_total);
     }

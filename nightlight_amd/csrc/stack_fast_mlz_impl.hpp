@@ -120,6 +120,7 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     using L = MlzLayout<LPP, WINSOR, NTOP>;
     constexpr int NS = L::NS, PW = L::PW, KL = L::KL, KH = L::KH, CR = L::CR, H0 = L::H0, W0 = L::W0;
     __shared__ float lds[L::ROWS * PW];
+    fused_prologue_dominant(p);
 
     const int lane = threadIdx.x & 63;
     const int role = threadIdx.x % LPP;

@@ -34,7 +34,22 @@ struct StackArgs {
     // (what the generic pass added) -- no host-enqueued snapshot copy between the kernels
     unsigned *list_snap;
     int list_part;
+    // Fused pass protocol of the sigma / winsorized fast path (nlstack_api.hip): no memset before and no
+    // reduction kernel after a pass.  The dominant kernel's first workgroup zeroes `final` and the scratch set
+    // of the NEXT pass (`zero_next`, kScratchWords words: the sets alternate); the dominant kernel adds its
+    // clip counts to this pass's sharded `partial` slots; the first workgroup of the generic pass sums them
+    // into `final`; every kernel after the dominant one (generic pass, replays) adds to `final` directly.
+    // The replays add to one address, which is only cheap while their lists are short (thousands of workgroups
+    // adding to one word take longer than a reduction kernel): nlstack_api.hip runs a pass fused only if the last
+    // finished pass reported a short exact list.  All nullptr: the plain protocol (memset, sharded slots,
+    // reduce_counters_kernel).
+    unsigned long long *final;    // [2] clip totals of the pass
+    unsigned long long *zero_next;
 };
+
+// words (64 bit) of one per-pass scratch set: clip accumulators + {exact-list length, generic-list length,
+// list snapshot, spare} (32 bit each)
+constexpr int kScratchWords = 2 * kClipSlots + 2;
 
 // fallback list written by the fast kernels, consumed by the exact kernel
 struct FastArgs {
@@ -140,8 +155,10 @@ int exact_plan(int mode, bool weighted, int n_frames, int n_pad, int max_lanes, 
                size_t *lds_bytes);
 hipError_t launch_stack_exact(int mode, bool weighted, StackArgs &args, int lanes, int grid,
                               size_t lds_bytes, hipStream_t stream, const char **name);
+// list_counts (optional): {exact-list length, generic-list length} of the pass, left in counters[2] (low | high << 32)
 hipError_t launch_reduce_counters(const unsigned long long *partial, int n_blocks,
-                                  unsigned long long *counters, hipStream_t stream);
+                                  unsigned long long *counters, hipStream_t stream,
+                                  const unsigned *list_counts = nullptr);
 
 // ---- stack_fast.hip ----
 // one-lane register kernels address a group of 4 frames through one buffer descriptor with

@@ -151,6 +151,10 @@ class StackHandle:
         """Force the bit-exact kernels (verification); default is the fast path."""
         capi.check(self._lib.nl_stack_set_exact(self._h, int(on)))
 
+    def set_dev_flags(self, flags):
+        """A/B switches of the fast path (include/nlstack.h: nl_stack_set_dev_flags)."""
+        capi.check(self._lib.nl_stack_set_dev_flags(self._h, int(flags)))
+
     @property
     def last_fallback_pixels(self):
         return int(self._lib.nl_stack_last_fallback_pixels(self._h))

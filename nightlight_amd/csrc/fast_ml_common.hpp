@@ -47,6 +47,14 @@ __device__ __forceinline__ int quad_or(int x)
     return x;
 }
 
+// the pixel's lane `R`, in every lane of the pixel
+template <int LPP, int R>
+__device__ __forceinline__ int quad_bcast(int x)
+{
+    if constexpr (LPP == 2) return dpp_i<R == 0 ? 0xA0 : 0xF5>(x);            // quad_perm [0,0,2,2] / [1,1,3,3]
+    else return dpp_i<R == 0 ? 0x00 : (R == 1 ? 0x55 : (R == 2 ? 0xAA : 0xFF))>(x);
+}
+
 // in-lane half-cleaners of a bitonic merge: distances NS/2 ... 1, ascending
 template <int NS, int D, int CH = 32>
 __device__ __forceinline__ void half_clean(float (&v)[NS])
@@ -180,9 +188,11 @@ __device__ __forceinline__ void ml_sort_merge(float (&v)[NS], int role)
 // lane's column and merge the runs: afterwards lane r holds global ranks [r*NS, r*NS+NS)
 // (+Inf for missing samples at the top).  Returns the number of valid samples of the pixel.
 // ENDS_ONLY: the last merge orders only the KEEP lowest / highest ranks of every lane.
-template <int LPP, int NS, bool ENDS_ONLY, int KEEP = 16, int CH = 32>
-__device__ __forceinline__ int ml_gather_sorted(const float *frames, int64_t stride, int N, bool on, int64_t pix,
-                                                int role, float (&v)[NS])
+// The gather alone: the lane's samples as loaded, NaN and missing frames as +Inf; returns the number of valid
+// samples of the PIXEL (all its lanes).
+template <int LPP, int NS>
+__device__ __forceinline__ int ml_gather_raw(const float *frames, int64_t stride, int N, bool on, int64_t pix,
+                                             int role, float (&v)[NS])
 {
 int nan_cnt = 0;
 {
@@ -232,8 +242,16 @@ int nan_cnt = 0;
             });
         }
     }
-    ml_sort_merge<LPP, NS, ENDS_ONLY, KEEP, CH>(v, role);
     return quad_sum<LPP>(NS - nan_cnt);
+}
+
+template <int LPP, int NS, bool ENDS_ONLY, int KEEP = 16, int CH = 32>
+__device__ __forceinline__ int ml_gather_sorted(const float *frames, int64_t stride, int N, bool on, int64_t pix,
+                                                int role, float (&v)[NS])
+{
+    const int n = ml_gather_raw<LPP, NS>(frames, stride, N, on, pix, role, v);
+    ml_sort_merge<LPP, NS, ENDS_ONLY, KEEP, CH>(v, role);
+    return n;
 }
 
 }  // namespace nl

@@ -63,53 +63,212 @@ struct MlzLayout {
     static constexpr int CR = WINSOR ? 16 : 8;                  // ranks read per side and pass for the clip decisions
     static constexpr int KL = WINSOR ? (LPP == 4 ? 64 : 32) : 24;          // low column : ranks [0, KL)
     static constexpr int KH = (WINSOR ? (LPP == 4 ? 72 : 40) : 32) + (FULL ? 0 : 8);   // high column: ranks [NTOP-KH, NTOP)
+    // SELECT: the columns and the median window are SELECTED from the lanes' sorted runs (select_ends / select_window below)
+    // instead of read off a full cross-lane merge -- stacks that fill their lanes, plain sigma clipping
+#ifdef NL_NO_SELECT
+    static constexpr bool SELECT = false;                       // (A/B builds: tools/ab_lib.sh)
+#else
+    // (four lanes per pixel only: with two the full merge is one cross-lane stage and measures 4 % faster)
+    static constexpr bool SELECT = FULL && !WINSOR && LPP == 4;
+#endif
+    static constexpr int KE = 32;                               // SELECT: ranks selected per end (>= KL, KH)
+    static constexpr int KLS = SELECT ? KE : KL;                // LDS rows of the low column
     static constexpr int GL = KL / 4 + 1, GH = KH / 4 + 1;      // table entries
     // median window: kk = a + (b-a)/2 and kk-1 over all a < ZLC, b > NTOP - ZHC
     static constexpr int TOPW = ZHC / 2 + 2, BOTW = ZLC / 2 + 2, MW = TOPW + BOTW;
     static constexpr int W0 = NTOP / 2 - TOPW;                  // rank of window slot 0
     static constexpr int H0 = NTOP - KH;                        // rank of high-column slot 0
     // LDS rows, one float per pixel each
-    static constexpr int XL = 0, XH = XL + KL, SL1 = XH + KH, SL2 = SL1 + GL, SH1 = SL2 + GL, SH2 = SH1 + GH,
-                         XW = SH2 + GH, ROWS = XW + MW;
+    // (SELECT stores whole selected runs with per-lane strides: 2 spare rows in front of the window, 8 behind it)
+    static constexpr int XL = 0, XH = XL + KLS, SL1 = XH + KH, SL2 = SL1 + GL, SH1 = SL2 + GL, SH2 = SH1 + GH,
+                         XW = SH2 + GH + (SELECT ? 2 : 0), ROWS = XW + MW + (SELECT ? 8 : 0);
     // roundings a term of the moment sums can see: fixed part (4 accumulators + quad adds), tables, assembly
     static constexpr int ROUNDINGS = (NS / 4 + 10 > KH + 4 ? NS / 4 + 10 : KH + 4) + 12;
     static_assert(NTOP % 16 == 0 && NTOP > NT / 2 && NTOP <= NT, "frame-count class");
     static_assert(KL % 8 == 0 && KH % 8 == 0 && KL >= ZLC + CR && KH >= ZHC + CR, "column sizes");
     static_assert(KL <= NS && KL <= H0 && W0 >= KL && W0 + MW <= H0 + KH, "columns and window inside the ranks in use");
+    static_assert(!SELECT || (KL <= KE && KH == KE && TOPW <= 14 && BOTW <= 10 && PADS < KE), "selection sizes");
 };
 
-// the pixel's lane `R`, in every lane of the pixel
-template <int LPP, int R>
-__device__ __forceinline__ int quad_bcast(int x)
+// ---- DPP minima / maxima: "mine" against the partner lane's "theirs" in ONE instruction ----
+// (inline asm: the compiler's hazard recognizer does not look inside -- a VALU write of a register needs two
+// wait states before a DPP read of it.  Every stage below starts with dpp_stage_begin() and only reads, through
+// DPP, registers written before it.)
+__device__ __forceinline__ void dpp_stage_begin()
 {
-    if constexpr (LPP == 2) return dpp_i<R == 0 ? 0xA0 : 0xF5>(x);            // quad_perm [0,0,2,2] / [1,1,3,3]
-    else return dpp_i<R == 0 ? 0x00 : (R == 1 ? 0x55 : (R == 2 ? 0xAA : 0xFF))>(x);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
+}
+#define NL_DPP2(name, op, m0, m1, perm)                                                                              \
+    __device__ __forceinline__ float name(float theirs, float mine)                                                  \
+    {                                                                                                                \
+        float r;                                                                                                     \
+        asm(op " %0, " m0 "%1, " m1 "%2 quad_perm:" perm " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(theirs), "v"(mine)); \
+        return r;                                                                                                    \
+    }
+NL_DPP2(min_swap1, "v_min_f32_dpp", "", "", "[1,0,3,2]")            // min(mine, partner ^ 1)
+NL_DPP2(min_swap1_nn, "v_min_f32_dpp", "-", "-", "[1,0,3,2]")       // min(-mine, -partner ^ 1)
+NL_DPP2(min_swap1_n, "v_min_f32_dpp", "-", "", "[1,0,3,2]")         // min(mine, -partner ^ 1)
+NL_DPP2(min_swap2, "v_min_f32_dpp", "", "", "[2,3,0,1]")            // min(mine, partner ^ 2)
+NL_DPP2(max_swap2, "v_max_f32_dpp", "", "", "[2,3,0,1]")            // max(mine, partner ^ 2)
+NL_DPP2(min_mirror_n, "v_min_f32_dpp", "-", "", "[3,2,1,0]")        // min(mine, -partner 3 - lane)
+#undef NL_DPP2
+
+// ascending half-cleaner cascade of a bitonic sequence (distances D, D/2 ... 1), raw min / max
+template <int N, int D>
+__device__ __forceinline__ void clean_raw(float (&x)[N])
+{
+    if constexpr (D >= 1) {
+        static_range<0, N / 2>([&](auto T) NL_INL {
+            constexpr int t = decltype(T)::value;
+            constexpr int i = ((t & ~(D - 1)) << 1) | (t & (D - 1));
+            constexpr int l = i | D;
+            const float lo = min_raw(x[i], x[l]), hi = max_raw(x[i], x[l]);
+            x[i] = lo;
+            x[l] = hi;
+        });
+        clean_raw<N, (D >> 1)>(x);
+    }
+}
+
+// SELECT front end (stacks that fill their lanes, plain sigma clipping).  After the in-lane sort every lane
+// holds a sorted run of NS samples; the clipping rounds only ever look at
+//   * the KL lowest / KH highest ranks of the pixel: they lie among the KE lowest / highest samples of the
+//     lanes' runs -- ALWAYS -- so a bitonic selection over those (KE per lane, two cross-lane stages) yields
+//     them; even lanes select the low end while the odd lanes select the high end on NEGATED samples (one
+//     instruction stream: min everywhere),
+//   * the ranks the median can take: the middle 64 samples of every run are merged (lower halves in the plain
+//     lanes, upper halves, negated, in the others) and only the 16 ranks either side of the middle are sorted
+//     out.  Rank = position in that merge + LPP * 32 holds iff no sample below a run's middle 64 exceeds, and
+//     none above them is below, the window: checked, pixels that fail go to the generic pass (a run's 25 % /
+//     75 % quantile would have to cross the pixel's median: 6 sigma of its sampling noise at 128 samples),
+//   * the moments of everything between the columns: summed with the ends of the runs clamped to the
+//     innermost column values [t_lo, t_hi] -- a sample inside a column contributes a known constant, taken off
+//     afterwards (its magnitude is the bulk's, not an outlier's: no cancellation to speak of; the extra
+//     rounding is covered by q_cancel in the error bound).
+// Cost: about 1 700 instructions instead of 2 500 for merge + staging + masked moments.
+template <class L, int LPP, int NS>
+__device__ __forceinline__ void select_ends(const float (&v)[NS], int role, float *col, float &t_lo, float &t_hi)
+{
+    constexpr int PW = L::PW, KE = L::KE;
+    const bool odd = (role & 1) != 0;
+    const int sgn = odd ? (int)0x80000000 : 0;
+    float z[KE];
+    dpp_stage_begin();
+    static_range<0, KE>([&](auto I) NL_INL {
+        constexpr int i = decltype(I)::value;
+        const float lo = min_swap1(v[KE - 1 - i], v[i]);                        // KE smallest of the pair's low ends
+        const float hn = min_swap1_nn(v[NS - KE + i], v[NS - 1 - i]);           // -(KE largest of the pair's high ends)
+        z[i] = odd ? hn : lo;
+    });
+    clean_raw<KE, KE / 2>(z);
+    if constexpr (LPP == 4) {
+        dpp_stage_begin();
+        static_range<0, KE / 2>([&](auto I) NL_INL {                            // (pairs, in place: short live ranges)
+            constexpr int i = decltype(I)::value, j = KE - 1 - i;
+            const float a = min_swap2(z[j], z[i]), b = min_swap2(z[i], z[j]);
+            z[i] = a;
+            z[j] = b;
+        });
+        clean_raw<KE, KE / 2>(z);
+    }
+    // even lanes: z[i] = rank i; odd lanes: z[i] = -(rank NTOP-1-i).  Rows: low column XL + i, high column XH + KE-1-i
+    float *dst = col + (odd ? (L::XH + KE - 1) * PW : L::XL * PW);
+    const int step = odd ? -PW : PW;
+    static_range<0, KE>([&](auto I) NL_INL {
+        constexpr int i = decltype(I)::value;
+        dst[i * step] = __int_as_float(__float_as_int(z[i]) ^ sgn);
+    });
+    // innermost column values, in every lane of the pixel
+    const float tl = z[L::KL - 1];                                              // rank KL-1 (even lanes)
+    const float th = __int_as_float(__float_as_int(z[KE - 1]) ^ (int)0x80000000);          // rank NTOP-KE (odd lanes)
+    t_lo = __int_as_float(quad_bcast<LPP, 0>(__float_as_int(tl)));
+    t_hi = __int_as_float(quad_bcast<LPP, 1>(__float_as_int(th)));
+}
+
+// the median window; consumes the runs' middles (v is dead afterwards)
+template <class L, int LPP, int NS>
+__device__ __forceinline__ void select_window(float (&v)[NS], int role, float *col, bool &window_ok)
+{
+    constexpr int PW = L::PW;
+    const bool odd = (role & 1) != 0;
+    const int sgn = odd ? (int)0x80000000 : 0;
+    constexpr int C0 = NS / 4, CN = NS / 2;                                     // candidates: run positions [32, 96)
+    // largest sample below / smallest above the candidates of any run of the pixel
+    float below = v[C0 - 1], above = v[C0 + CN];
+    below = fmaxf(below, dpp_f<kSwap1>(below));
+    above = fminf(above, dpp_f<kSwap1>(above));
+    if constexpr (LPP == 4) {
+        below = fmaxf(below, dpp_f<kSwap2>(below));
+        above = fminf(above, dpp_f<kSwap2>(above));
+    }
+    float t[CN];
+    static_range<0, CN>([&](auto I) NL_INL {
+        constexpr int i = decltype(I)::value;
+        t[i] = __int_as_float(__float_as_int(v[C0 + i]) ^ sgn);                 // odd lanes work on negated samples
+    });
+    dpp_stage_begin();
+    static_range<0, CN / 2>([&](auto I) NL_INL {
+        constexpr int i = decltype(I)::value, j = CN - 1 - i;
+        // plain lanes: lower half of the pair's 128 candidates, the others: -(upper half)
+        const float a = min_swap1_n(t[j], t[i]), b = min_swap1_n(t[i], t[j]);
+        t[i] = a;
+        t[j] = b;
+    });
+    float w[16];
+    if constexpr (LPP == 4) {
+        clean_raw<CN, CN / 2>(t);                          // sorted: lanes 0 / 2 ascending lower halves, 1 / 3 ascending -(upper halves)
+        dpp_stage_begin();
+        static_range<0, CN>([&](auto I) NL_INL {
+            constexpr int i = decltype(I)::value;
+            t[i] = min_mirror_n(t[i], t[i]);               // lanes 0, 2: lower 128 of the 256 candidates; 1, 3: -(upper 128)
+        });
+        dpp_stage_begin();
+        // the 64 largest of the (bitonic) lower 128 / of -(upper 128): partner lane ^ 2, mirrored index; of those
+        // (bitonic again) the 32 largest, then the 16 largest
+        float m2[CN / 2];
+        static_range<0, CN / 2>([&](auto I) NL_INL {
+            constexpr int i = decltype(I)::value;
+            const float a = max_swap2(t[CN - 1 - i], t[i]);                     // position i of the 64 largest
+            const float b = max_swap2(t[CN / 2 - 1 - i], t[i + CN / 2]);        // position i + 32
+            m2[i] = max_raw(a, b);
+        });
+        static_range<0, 16>([&](auto I) NL_INL {
+            constexpr int i = decltype(I)::value;
+            w[i] = max_raw(m2[i], m2[i + 16]);
+        });
+    } else {
+        // two lanes: t is the (bitonic) lower / -(upper) 64 of the 128 candidates: its 16 largest
+        float m2[CN / 2];
+        static_range<0, CN / 2>([&](auto I) NL_INL {
+            constexpr int i = decltype(I)::value;
+            m2[i] = max_raw(t[i], t[i + CN / 2]);
+        });
+        static_range<0, 16>([&](auto I) NL_INL {
+            constexpr int i = decltype(I)::value;
+            w[i] = max_raw(m2[i], m2[i + 16]);
+        });
+    }
+    clean_raw<16, 8>(w);
+    // plain lanes: w[j] = candidate rank (LPP * 32 - 16) + j, i.e. window slot j - 2 for j >= 2; the other lanes:
+    // w[j] = -(candidate rank LPP * 32 + 15 - j), window slot 14 + 15 - j (slots up to MW - 1: j >= 6).  The rows
+    // outside the window are spare (MlzLayout).
+    float *dst = col + (odd ? (L::XW + 29) * PW : (L::XW - 2) * PW);
+    const int step = odd ? -PW : PW;
+    static_range<0, 16>([&](auto J) NL_INL {
+        constexpr int j = decltype(J)::value;
+        dst[j * step] = __int_as_float(__float_as_int(w[j]) ^ sgn);
+    });
+    // window slot 0 must not be below `below`, slot MW-1 not above `above`
+    const float w_first = __int_as_float(quad_bcast<LPP, 0>(__float_as_int(w[2])));
+    const float w_last = __int_as_float(quad_bcast<LPP, 1>(__float_as_int(w[6]) ^ (int)0x80000000));
+    window_ok = below <= w_first && w_last <= above;
 }
 
 // LDS operations of one wave complete in order; the clobber keeps the compiler from moving
 // loads of other lanes' stores across this point
 __device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-// sum of (v[k]-c) and (v[k]-c)^2 over k in [B, E), four accumulators
-template <int B, int E, int NS>
-__device__ __forceinline__ void seg_moments(const float (&v)[NS], float c, float &d, float &q)
-{
-    float d0 = 0, d1 = 0, d2 = 0, d3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    constexpr int M = (E - B) / 4;
-    static_chunks<0, M, 4>([&](auto K) NL_INL {
-        constexpr int k = B + 4 * decltype(K)::value;
-        const float e0 = v[k] - c, e1 = v[k + 1] - c, e2 = v[k + 2] - c, e3 = v[k + 3] - c;
-        d0 += e0; d1 += e1; d2 += e2; d3 += e3;
-        q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
-        q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
-    });
-    static_range<B + 4 * M, E>([&](auto K) NL_INL {
-        const float e = v[decltype(K)::value] - c;
-        d0 += e; q0 = __builtin_fmaf(e, e, q0);
-    });
-    d = (d0 + d1) + (d2 + d3);
-    q = (q0 + q1) + (q2 + q3);
-}
 
 }  // namespace
 
@@ -134,7 +293,13 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     // a stack that fills its lanes: the last merge orders the 32 lowest / highest ranks of every lane
     // (columns of the plain sigma kernel, median window); the winsorized columns are longer, and the
     // columns of a shorter stack sit inside the lanes: full merge
-    const int n = ml_gather_sorted<LPP, NS, L::FULL && !WINSOR, 32>(p.frames, p.stride, N, on, pix, role, v);
+    int n;
+    if constexpr (L::SELECT) {
+        n = ml_gather_raw<LPP, NS>(p.frames, p.stride, N, on, pix, role, v);
+        sort_network<NS>(v);                               // the lanes' runs are not merged: select_ends / select_window
+    } else {
+        n = ml_gather_sorted<LPP, NS, L::FULL && !WINSOR, 32>(p.frames, p.stride, N, on, pix, role, v);
+    }
 
     // ---- columns and median window to LDS ----
     // (no divergent branches while the column is in registers -- they cost the compiler's register
@@ -143,6 +308,43 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     auto bcast_f = [](auto R, float x) NL_INL {
         return __int_as_float(quad_bcast<LPP, decltype(R)::value>(__float_as_int(x)));
     };
+    bool window_ok = true;
+    float d_fix = 0.0f, q_fix = 0.0f;                      // moments of the ranks between the columns
+    float q_cancel = 0.0f;                                 // SELECT: squares taken off again (enters the rounding bound)
+    float c_sel = 0.0f;
+    if constexpr (L::SELECT) {
+        // shift: the middle of the first lane's run (any value near the bulk works)
+        c_sel = bcast_f(std::integral_constant<int, 0>{}, v[NS / 2]);
+        float t_lo, t_hi;                                  // innermost values of the low / high column
+        select_ends<L, LPP, NS>(v, role, col, t_lo, t_hi);
+        // moments of every sample of the pixel, the ends of the runs clamped to [t_lo, t_hi]: the KL + KH samples
+        // of the columns count as t_lo / t_hi (a missing sample, +Inf, as t_hi) and are taken off again
+        {
+            const float c = c_sel;
+            float d0 = 0, d1 = 0, d2 = 0, d3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+            static_chunks<0, NS / 4, 4>([&](auto K4) NL_INL {
+                constexpr int k = 4 * decltype(K4)::value;
+                auto term = [&](auto KK) NL_INL {
+                    constexpr int kk = decltype(KK)::value;
+                    if constexpr (kk < L::KE) return max_raw(v[kk], t_lo) - c;
+                    else if constexpr (kk >= NS - L::KE) return min_raw(v[kk], t_hi) - c;
+                    else return v[kk] - c;
+                };
+                const float e0 = term(std::integral_constant<int, k>{}), e1 = term(std::integral_constant<int, k + 1>{});
+                const float e2 = term(std::integral_constant<int, k + 2>{}), e3 = term(std::integral_constant<int, k + 3>{});
+                d0 += e0; d1 += e1; d2 += e2; d3 += e3;
+                q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
+                q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
+            });
+            const float d_all = quad_sum<LPP>((d0 + d1) + (d2 + d3));
+            const float q_all = quad_sum<LPP>((q0 + q1) + (q2 + q3));
+            const float e_lo = t_lo - c, e_hi = t_hi - c;
+            q_cancel = (float)KL * (e_lo * e_lo) + (float)KH * (e_hi * e_hi);
+            d_fix = d_all - ((float)KL * e_lo + (float)KH * e_hi);
+            q_fix = q_all - q_cancel;
+        }
+        select_window<L, LPP, NS>(v, role, col, window_ok);
+    } else {
     static_range<0, KL>([&](auto K) NL_INL {
         constexpr int k = decltype(K)::value;
         col[(L::XL + k) * PW] = bcast_f(std::integral_constant<int, 0>{}, v[k]);
@@ -155,17 +357,20 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         constexpr int k = decltype(K)::value, r = W0 + k;
         col[(L::XW + k) * PW] = bcast_f(std::integral_constant<int, r / NS>{}, v[r % NS]);
     });
+    }
     lds_settle();
 
     bool active = on && n > 0;
-    // the alive window must keep its ends inside the columns: at most PADS missing samples
-    bool to_generic = active && !(n > NTOP - 1 - L::PADS);
+    // the alive window must keep its ends inside the columns: at most PADS missing samples (SELECT: and the
+    // median window must have come out of the runs' middles)
+    bool to_generic = active && (!(n > NTOP - 1 - L::PADS) || !window_ok);
     if (to_generic && role == 0) NL_STAT(0, 1);
     active = active && !to_generic;
     bool to_exact = false;
 
     // shift c = first-pass median (any value near the bulk works)
-    const float c = col[(L::XW + min(max((n >> 1) - W0, 0), L::MW - 1)) * PW];
+    float c = col[(L::XW + min(max((n >> 1) - W0, 0), L::MW - 1)) * PW];
+    if constexpr (L::SELECT) c = c_sel;
 
     // ---- tables: sums from the inner end of each column outwards, every 4th position ----
     // (read back from LDS: the high column of a stack that does not fill its lanes spans two lanes;
@@ -205,8 +410,7 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     // ---- moments of the ranks between the columns (never clipped, never clamped) ----
     // blocks of 8 registers; a block of lane `role` counts if its ranks lie in [KL, H0) (both multiples of 8):
     // the rest is a column, or padding above the ranks in use
-    float d_fix, q_fix;
-    {
+    if constexpr (!L::SELECT) {
         float da[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qa[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         const int off = role * NS - KL;
         static_chunks<0, NS / 8, 2>([&](auto J) NL_INL {
@@ -226,8 +430,8 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         q_fix = quad_sum<LPP>((qa[0] + qa[1]) + (qa[2] + qa[3]));
     }
     // rank KL (first above the low column) and rank H0-1 (last below the high column)
-    float x_in_lo, x_in_hi;
-    {
+    float x_in_lo = 0.0f, x_in_hi = 0.0f;                 // (only the winsorized rounds look at them)
+    if constexpr (WINSOR) {
         x_in_lo = bcast_f(std::integral_constant<int, KL / NS>{}, v[KL % NS]);
         x_in_hi = bcast_f(std::integral_constant<int, (H0 - 1) / NS>{}, v[(H0 - 1) % NS]);
     }
@@ -290,7 +494,9 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
 
         // ---- bracket the reference's stddev ----
         const float amax = fmaxf(fabsf(xl[0]), fabsf(xh[0]));
-        const float err_o = kErrF * kU * (aa + bb);
+        // (SELECT: d_fix / q_fix carry the rounding of the column samples that were summed at [t_lo, t_hi] and
+        // taken off again: their squares join the magnitude the bound scales with)
+        const float err_o = L::SELECT ? (1.15f * kErrF) * kU * ((aa + bb) + q_cancel / fcnt) : kErrF * kU * (aa + bb);
         const float eps_r = 1.02f * (fcnt + 8.0f) * kU;
         const float e_m = 1.02f * (fcnt + 2.0f) * kU * amax;
         const float v_up = var + err_o;

@@ -3,7 +3,8 @@
 Randomised differential test (run on the GPU box): random frame counts, modes, sigmas, NaN
 fractions, ties, infinities and tile geometry through the default dispatch of the C ABI against
 the oracle.  Counters must be identical, values bit-exact or within 1e-5 depending on the kernel.
-usage: fuzz_parity.py [cases] [seed]"""
+usage: fuzz_parity.py [cases] [seed]
+NL_FUZZ_N=lo,hi restricts the frame counts, NL_FUZZ_MODES=2,3 the modes (a kernel class under test)."""
 import os
 import sys
 import time
@@ -25,6 +26,11 @@ for i in range(cases):
     mode = int(rng.choice([0, 1, 2, 2, 3, 3, 4, 5, 5]))
     n = int(rng.choice([rng.integers(1, 33), rng.integers(33, 129), rng.integers(129, 513), rng.integers(513, 700)],
                        p=[0.35, 0.35, 0.25, 0.05]))
+    if os.environ.get("NL_FUZZ_N"):
+        lo_n, hi_n = (int(x) for x in os.environ["NL_FUZZ_N"].split(","))
+        n = int(rng.integers(lo_n, hi_n + 1))
+    if os.environ.get("NL_FUZZ_MODES"):
+        mode = int(rng.choice([int(x) for x in os.environ["NL_FUZZ_MODES"].split(",")]))
     width, height = int(rng.integers(3, 150)), int(rng.integers(1, 12))
     row0 = int(rng.integers(0, height))
     rows = int(rng.integers(1, height - row0 + 1))

@@ -219,6 +219,14 @@ void nl_group_destroy(nl_group_t *g);
 int nl_group_size(nl_group_t *g);
 nl_stack_t *nl_group_tile(nl_group_t *g, int t);            /* borrowed, owned by the group */
 int nl_group_upload_frame(nl_group_t *g, int idx, const float *host_frame);   /* overlapped, pointer not retained */
+/* The ingest fast paths on the group (rows F3 / F4: internal/fits/read.go:351-395, project.go:26-76), overlapped
+ * like nl_group_upload_frame -- one host thread per tile stages its share, nothing is awaited on the devices.
+ * raw_host: the big-endian payload of the WHOLE frame (every tile takes the byte range of its rows);
+ * src_host: the whole unaligned source frame (every tile projects its own rows). */
+int nl_group_upload_frame_fits(nl_group_t *g, int idx, const void *raw_host, int bitpix, float bscale, float bzero,
+                               float multiplier, float offset);
+int nl_group_upload_frame_projected(nl_group_t *g, int idx, const float *src_host, int src_w, int src_h,
+                                    const float trans[6], float out_of_bounds, float multiplier, float offset);
 int nl_group_fill_synthetic(nl_group_t *g, uint64_t seed);
 int nl_group_set_active_frames(nl_group_t *g, int n);
 int nl_group_set_weights(nl_group_t *g, const float *weights);
@@ -275,6 +283,14 @@ int nl_stack_upload_frame_fits(nl_stack_t *h, int idx, const void *raw_host, int
  * the reference's fp32 expressions; destination pixels whose taps leave the
  * source get out_of_bounds (NaN in the pipeline = "no data" for the stack).
  * Only the handle's rows are produced.  multiplier/offset as above. */
+/* Overlapped forms of the two calls above (no statistics): the bytes go through the pinned staging ring of
+ * nl_stack_upload_frame_async, the DMA, the decode / projection kernel run on the copy stream, the call returns
+ * without waiting for the device; the next nl_stack_run* waits for them on the device. */
+int nl_stack_upload_frame_fits_async(nl_stack_t *h, int idx, const void *raw_host, int bitpix,
+                                     float bscale, float bzero, float multiplier, float offset);
+int nl_stack_upload_frame_projected_async(nl_stack_t *h, int idx, const float *src_host, int src_w, int src_h,
+                                          const float trans[6], float out_of_bounds, float multiplier,
+                                          float offset);
 int nl_stack_upload_frame_projected(nl_stack_t *h, int idx, const float *src_host, int src_w,
                                     int src_h, const float trans[6], float out_of_bounds,
                                     float multiplier, float offset);

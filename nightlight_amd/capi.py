@@ -46,6 +46,8 @@ EXPORTS = [
     "nl_stack_frame_stats", "nl_stack_frame_noise", "nl_stack_weights_from_noise",
     "nl_median_filter_3x3", "nl_median_filter_mask",
     "nl_stack_upload_frame_fits", "nl_stack_upload_frame_projected", "nl_stack_frame_affine",
+    "nl_stack_upload_frame_fits_async", "nl_stack_upload_frame_projected_async",
+    "nl_group_upload_frame_fits", "nl_group_upload_frame_projected",
     "nl_stack_download_result_fits", "nl_fits_decode", "nl_project_bilinear",
     "nl_host_op_stack_apply_json", "nl_host_op_stack_roundtrip_json", "nl_host_set_devices",
     "nl_host_op_stack_batches_apply_json",
@@ -158,6 +160,12 @@ def load():
     L.nl_stack_upload_wait.argtypes = [vp]
     L.nl_stack_upload_frame_fits.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, C.c_float,
                                              C.c_float, _f32p]
+    L.nl_stack_upload_frame_fits_async.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.nl_group_upload_frame_fits.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.nl_stack_upload_frame_projected_async.argtypes = [vp, C.c_int, _f32p, C.c_int, C.c_int, _f32p, C.c_float,
+                                                          C.c_float, C.c_float]
+    L.nl_group_upload_frame_projected.argtypes = [vp, C.c_int, _f32p, C.c_int, C.c_int, _f32p, C.c_float,
+                                                   C.c_float, C.c_float]
     L.nl_stack_upload_frame_projected.argtypes = [vp, C.c_int, _f32p, C.c_int, C.c_int, _f32p, C.c_float,
                                                   C.c_float, C.c_float]
     L.nl_stack_frame_affine.argtypes = [vp, C.c_int, C.c_float, C.c_float]

@@ -114,6 +114,10 @@ struct nl_stack {
     size_t ingest_bytes = 0;
     // asynchronous uploads: pinned staging ring + copy stream (nl_stack_upload_frame_async)
     hipStream_t copy_stream = nullptr;
+    size_t stage_cap[kStageSlots] = {0, 0, 0, 0};
+    void *d_ingest_async = nullptr;            // raw bytes / source frame of the overlapped ingest (copy stream)
+    size_t ingest_async_bytes = 0;
+    double *d_stat_partial_async = nullptr;
     void *h_stage[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t stage_done[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
     bool stage_used[kStageSlots] = {false, false, false, false};
@@ -160,6 +164,8 @@ static int destroy_impl(nl_stack_t *h)
     if (h->d_counters) (void)hipFree(h->d_counters);
     if (h->d_stat_partial) (void)hipFree(h->d_stat_partial);
     if (h->d_ingest) (void)hipFree(h->d_ingest);
+    if (h->d_ingest_async) (void)hipFree(h->d_ingest_async);
+    if (h->d_stat_partial_async) (void)hipFree(h->d_stat_partial_async);
     for (int i = 0; i < 2; i++) {
         if (h->d_lf_list[i]) (void)hipFree(h->d_lf_list[i]);
         if (h->d_lf_state[i]) (void)hipFree(h->d_lf_state[i]);
@@ -310,14 +316,12 @@ int nl_stack_upload_tile(nl_stack_t *h, int idx, const float *host_tile)
 // and this call returns (the caller's pointer is not retained, cgo rules); the
 // DMA runs on its own stream while the caller prepares the next frame, and the
 // next stack pass waits for it on the device, not on the host.
-int nl_stack_upload_frame_async(nl_stack_t *h, int idx, const float *host_frame)
+// Overlapped uploads: `bytes` of host memory go into a pinned staging slot (ring of kStageSlots; a slot is
+// re-used once its last DMA has left it) and the call returns; the copy stream is ordered behind the last
+// pass that may still read the frames.  *staged = the pinned copy, *slot_out = its slot (record stage_done on
+// the copy stream after the last operation that reads it).
+static int stage_host_bytes(nl_stack_t *h, const void *src_v, size_t bytes, char **staged, int *slot_out)
 {
-    NL_CHECK_HANDLE(h);
-    if (idx < 0 || idx >= h->n_frames || !host_frame)
-        return fail(NL_ERR_INVALID_ARG, "upload_frame_async: bad index %d or null frame", idx);
-    if (h->d_frames != h->d_frames_owned)
-        return fail(NL_ERR_INVALID_ARG, "upload_frame_async: frames are attached, not owned");
-    const size_t bytes = (size_t)h->npix * sizeof(float);
     if (!h->copy_stream) NL_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     if (h->pass_seq > 0 && h->copy_waits_pass != h->pass_seq) {
         // a pass enqueued earlier may still be reading the frames: the copy stream waits for its
@@ -327,12 +331,14 @@ int nl_stack_upload_frame_async(nl_stack_t *h, int idx, const float *host_frame)
     }
     const int slot = h->stage_next;
     h->stage_next = (slot + 1) % kStageSlots;
-    if (!h->h_stage[slot]) {
-        NL_HIP(hipHostMalloc(&h->h_stage[slot], bytes, hipHostMallocDefault));
-        NL_HIP(hipEventCreateWithFlags(&h->stage_done[slot], hipEventDisableTiming));
-    }
     if (h->stage_used[slot]) NL_HIP(hipEventSynchronize(h->stage_done[slot]));     // its last DMA has left the buffer
-    const char *src = reinterpret_cast<const char *>(host_frame + (int64_t)h->row0 * h->width);
+    if (!h->stage_done[slot]) NL_HIP(hipEventCreateWithFlags(&h->stage_done[slot], hipEventDisableTiming));
+    if (h->stage_cap[slot] < bytes) {
+        if (h->h_stage[slot]) { NL_HIP(hipHostFree(h->h_stage[slot])); h->h_stage[slot] = nullptr; h->stage_cap[slot] = 0; }
+        NL_HIP(hipHostMalloc(&h->h_stage[slot], bytes, hipHostMallocDefault));
+        h->stage_cap[slot] = bytes;
+    }
+    const char *src = static_cast<const char *>(src_v);
     char *dst = static_cast<char *>(h->h_stage[slot]);
     if (bytes < ((size_t)4 << 20)) {
         memcpy(dst, src, bytes);
@@ -346,11 +352,33 @@ int nl_stack_upload_frame_async(nl_stack_t *h, int idx, const float *host_frame)
         memcpy(dst, src, part < bytes ? part : bytes);
         for (auto &w : workers) w.join();
     }
-    NL_HIP(hipMemcpyAsync(h->d_frames + (int64_t)idx * h->npix, dst, bytes, hipMemcpyHostToDevice, h->copy_stream));
+    *staged = dst;
+    *slot_out = slot;
+    return NL_OK;
+}
+
+static int stage_done(nl_stack_t *h, int slot)
+{
     NL_HIP(hipEventRecord(h->stage_done[slot], h->copy_stream));
     h->stage_used[slot] = true;
     h->uploads_pending = true;
     return NL_OK;
+}
+
+int nl_stack_upload_frame_async(nl_stack_t *h, int idx, const float *host_frame)
+{
+    NL_CHECK_HANDLE(h);
+    if (idx < 0 || idx >= h->n_frames || !host_frame)
+        return fail(NL_ERR_INVALID_ARG, "upload_frame_async: bad index %d or null frame", idx);
+    if (h->d_frames != h->d_frames_owned)
+        return fail(NL_ERR_INVALID_ARG, "upload_frame_async: frames are attached, not owned");
+    const size_t bytes = (size_t)h->npix * sizeof(float);
+    char *dst = nullptr;
+    int slot = 0;
+    int rc = stage_host_bytes(h, host_frame + (int64_t)h->row0 * h->width, bytes, &dst, &slot);
+    if (rc != NL_OK) return rc;
+    NL_HIP(hipMemcpyAsync(h->d_frames + (int64_t)idx * h->npix, dst, bytes, hipMemcpyHostToDevice, h->copy_stream));
+    return stage_done(h, slot);
 }
 
 // Host-side wait for every asynchronous upload issued so far.
@@ -1223,6 +1251,70 @@ int nl_stack_upload_frame_projected(nl_stack_t *h, int idx, const float *src_hos
                               out_of_bounds, affine, multiplier, offset, h->stream));
     NL_HIP(hipStreamSynchronize(h->stream));
     return NL_OK;
+}
+
+// device scratch of the overlapped ingest (copy stream: operations on it are stream-ordered, one buffer serves
+// every frame in flight)
+static int ingest_async_reserve(nl_stack_t *h, size_t bytes)
+{
+    if (!h->d_stat_partial_async) NL_HIP(hipMalloc(&h->d_stat_partial_async, sizeof(double) * 3 * kStatBlocks));
+    if (h->ingest_async_bytes >= bytes) return NL_OK;
+    if (h->copy_stream) NL_HIP(hipStreamSynchronize(h->copy_stream));
+    if (h->d_ingest_async) { NL_HIP(hipFree(h->d_ingest_async)); h->d_ingest_async = nullptr; h->ingest_async_bytes = 0; }
+    NL_HIP(hipMalloc(&h->d_ingest_async, bytes));
+    h->ingest_async_bytes = bytes;
+    return NL_OK;
+}
+
+int nl_stack_upload_frame_fits_async(nl_stack_t *h, int idx, const void *raw_host, int bitpix, float bscale,
+                                     float bzero, float multiplier, float offset)
+{
+    NL_CHECK_HANDLE(h);
+    if (idx < 0 || idx >= h->n_frames || !raw_host)
+        return fail(NL_ERR_INVALID_ARG, "upload_frame_fits: bad index %d or null payload", idx);
+    const int bpv = nl::fits_bytes_per_value(bitpix);
+    if (bpv == 0) return fail(NL_ERR_INVALID_ARG, "Unknown BITPIX value %d", bitpix);      // read.go:169
+    if (h->d_frames != h->d_frames_owned)
+        return fail(NL_ERR_INVALID_ARG, "upload_frame_fits: frames are attached, not owned");
+    const size_t bytes = (size_t)h->npix * (size_t)bpv;
+    char *staged = nullptr;
+    int slot = 0;
+    int rc = stage_host_bytes(h, raw_host, bytes, &staged, &slot);
+    if (rc != NL_OK) return rc;
+    rc = ingest_async_reserve(h, bytes);
+    if (rc != NL_OK) return rc;
+    NL_HIP(hipMemcpyAsync(h->d_ingest_async, staged, bytes, hipMemcpyHostToDevice, h->copy_stream));
+    const bool affine = !(multiplier == 1.0f && offset == 0.0f);
+    NL_HIP(nl::launch_fits_decode(h->d_ingest_async, bitpix, h->npix, bscale, bzero, affine, multiplier, offset,
+                                  h->d_frames + (int64_t)idx * h->npix, h->d_stat_partial_async, kStatBlocks,
+                                  h->copy_stream));
+    return stage_done(h, slot);
+}
+
+int nl_stack_upload_frame_projected_async(nl_stack_t *h, int idx, const float *src_host, int src_w, int src_h,
+                                          const float trans[6], float out_of_bounds, float multiplier, float offset)
+{
+    NL_CHECK_HANDLE(h);
+    if (idx < 0 || idx >= h->n_frames || !src_host || !trans || src_w < 1 || src_h < 1)
+        return fail(NL_ERR_INVALID_ARG, "upload_frame_projected: bad argument (frame %d)", idx);
+    if (h->d_frames != h->d_frames_owned)
+        return fail(NL_ERR_INVALID_ARG, "upload_frame_projected: frames are attached, not owned");
+    float inv[6];
+    int rc = invert_transform(trans, inv);
+    if (rc != NL_OK) return rc;
+    const size_t bytes = (size_t)src_w * (size_t)src_h * sizeof(float);
+    char *staged = nullptr;
+    int slot = 0;
+    rc = stage_host_bytes(h, src_host, bytes, &staged, &slot);
+    if (rc != NL_OK) return rc;
+    rc = ingest_async_reserve(h, bytes);
+    if (rc != NL_OK) return rc;
+    NL_HIP(hipMemcpyAsync(h->d_ingest_async, staged, bytes, hipMemcpyHostToDevice, h->copy_stream));
+    const bool affine = !(multiplier == 1.0f && offset == 0.0f);
+    NL_HIP(nl::launch_project(static_cast<const float *>(h->d_ingest_async), src_w, src_h,
+                              h->d_frames + (int64_t)idx * h->npix, h->width, h->row0, h->rows, inv,
+                              out_of_bounds, affine, multiplier, offset, h->copy_stream));
+    return stage_done(h, slot);
 }
 
 int nl_stack_frame_affine(nl_stack_t *h, int idx, float multiplier, float offset)

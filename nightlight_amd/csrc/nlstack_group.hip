@@ -14,6 +14,7 @@
 #include <stdio.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "stack_kernels.h"
@@ -70,16 +71,65 @@ nl_stack_t *nl_group_tile(nl_group_t *g, int t)
     return (g && t >= 0 && t < (int)g->tiles.size()) ? g->tiles[(size_t)t] : nullptr;
 }
 
+}  // extern "C"
+
+// Runs f(tile) for every tile, one host thread per tile beyond the first: staging a frame is a host memcpy
+// into pinned memory per tile, and with one tile per device a serial loop would feed one DMA engine at a time.
+// The first error (lowest tile) wins; its message becomes the calling thread's nl_last_error().
+template <class F>
+static int for_each_tile(nl_group_t *g, F &&f)
+{
+    const size_t n = g->tiles.size();
+    std::vector<int> rc(n, NL_OK);
+    std::vector<std::string> msg(n);
+    auto one = [&](size_t t) {
+        rc[t] = f(t);
+        if (rc[t] != NL_OK) msg[t] = nl_last_error();        // (thread-local: fetch it on the worker)
+    };
+    std::vector<std::thread> workers;
+    for (size_t t = 1; t < n; t++) workers.emplace_back(one, t);
+    if (n > 0) one(0);
+    for (auto &w : workers) w.join();
+    for (size_t t = 0; t < n; t++)
+        if (rc[t] != NL_OK) {
+            nl::set_last_error(msg[t].c_str());
+            return rc[t];
+        }
+    return NL_OK;
+}
+
+extern "C" {
+
 // every tile copies its rows out of the caller's frame into its own pinned staging buffer
-// (pointer not retained, cgo rules) and starts its DMA; nothing is awaited here
+// (pointer not retained, cgo rules) and starts its DMA; nothing is awaited on the devices
 int nl_group_upload_frame(nl_group_t *g, int idx, const float *host_frame)
 {
     if (!g) return NL_ERR_INVALID_ARG;
-    for (size_t t = 0; t < g->tiles.size(); t++) {
-        int rc = nl_stack_upload_frame_async(g->tiles[t], idx, host_frame);
-        if (rc != NL_OK) return rc;
-    }
-    return NL_OK;
+    return for_each_tile(g, [&](size_t t) { return nl_stack_upload_frame_async(g->tiles[t], idx, host_frame); });
+}
+
+// F3 on the group: raw_host = the big-endian FITS payload of the WHOLE frame (width*height values); every tile
+// takes the byte range of its rows (row-major: contiguous) through its pinned ring, decodes on its device
+int nl_group_upload_frame_fits(nl_group_t *g, int idx, const void *raw_host, int bitpix, float bscale, float bzero,
+                               float multiplier, float offset)
+{
+    if (!g || !raw_host) return NL_ERR_INVALID_ARG;
+    const int bpv = bitpix < 0 ? -bitpix / 8 : bitpix / 8;
+    return for_each_tile(g, [&](size_t t) {
+        const char *part = static_cast<const char *>(raw_host) + (size_t)g->row0[t] * (size_t)g->width * (size_t)bpv;
+        return nl_stack_upload_frame_fits_async(g->tiles[t], idx, part, bitpix, bscale, bzero, multiplier, offset);
+    });
+}
+
+// F4 on the group: every tile receives the whole unaligned source frame and projects its own rows
+int nl_group_upload_frame_projected(nl_group_t *g, int idx, const float *src_host, int src_w, int src_h,
+                                    const float trans[6], float out_of_bounds, float multiplier, float offset)
+{
+    if (!g) return NL_ERR_INVALID_ARG;
+    return for_each_tile(g, [&](size_t t) {
+        return nl_stack_upload_frame_projected_async(g->tiles[t], idx, src_host, src_w, src_h, trans, out_of_bounds,
+                                                     multiplier, offset);
+    });
 }
 
 int nl_group_fill_synthetic(nl_group_t *g, uint64_t seed)

@@ -279,6 +279,21 @@ class StackHandle:
             self._h, int(idx), capi.fptr(src), int(src_w), int(src_h), capi.fptr(t), float(out_of_bounds),
             float(multiplier), float(offset)))
 
+    def upload_frame_fits_async(self, idx, raw, bitpix, bscale=1.0, bzero=0.0, multiplier=1.0, offset=0.0):
+        """Overlapped form of upload_frame_fits (pinned ring, copy stream, no statistics)."""
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        capi.check(self._lib.nl_stack_upload_frame_fits_async(
+            self._h, int(idx), raw.ctypes.data_as(C.c_void_p), int(bitpix), float(bscale), float(bzero),
+            float(multiplier), float(offset)))
+
+    def upload_frame_projected_async(self, idx, src, src_w, src_h, trans, out_of_bounds=float("nan"),
+                                     multiplier=1.0, offset=0.0):
+        src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1)
+        t = np.ascontiguousarray(trans, dtype=np.float32).reshape(6)
+        capi.check(self._lib.nl_stack_upload_frame_projected_async(
+            self._h, int(idx), capi.fptr(src), int(src_w), int(src_h), capi.fptr(t), float(out_of_bounds),
+            float(multiplier), float(offset)))
+
     def frame_affine(self, idx, multiplier, offset):
         capi.check(self._lib.nl_stack_frame_affine(self._h, int(idx), float(multiplier), float(offset)))
 
@@ -335,6 +350,21 @@ class StackGroup:
             assert f.size == self.width * self.height
             capi.check(self._lib.nl_group_upload_frame(self._g, i, capi.fptr(f)))
 
+    def upload_frame_fits(self, idx, raw, bitpix, bscale=1.0, bzero=0.0, multiplier=1.0, offset=0.0):
+        """raw: big-endian FITS payload of the WHOLE frame; every tile decodes its rows on its device."""
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        capi.check(self._lib.nl_group_upload_frame_fits(
+            self._g, int(idx), raw.ctypes.data_as(C.c_void_p), int(bitpix), float(bscale), float(bzero),
+            float(multiplier), float(offset)))
+
+    def upload_frame_projected(self, idx, src, src_w, src_h, trans, out_of_bounds=float("nan"),
+                               multiplier=1.0, offset=0.0):
+        src = np.ascontiguousarray(src, dtype=np.float32).reshape(-1)
+        t = np.ascontiguousarray(trans, dtype=np.float32).reshape(6)
+        capi.check(self._lib.nl_group_upload_frame_projected(
+            self._g, int(idx), capi.fptr(src), int(src_w), int(src_h), capi.fptr(t), float(out_of_bounds),
+            float(multiplier), float(offset)))
+
     def fill_synthetic(self, seed=0x4E4C5354):
         capi.check(self._lib.nl_group_fill_synthetic(self._g, C.c_uint64(seed)))
 
@@ -345,12 +375,20 @@ class StackGroup:
     def set_exact(self, on=True):
         capi.check(self._lib.nl_group_set_exact(self._g, int(on)))
 
-    def run(self, mode, sigma_low=2.75, sigma_high=2.75, ref_loc=0.0):
-        out = np.zeros(self.width * self.height, np.float32)
+    def run(self, mode, sigma_low=2.75, sigma_high=2.75, ref_loc=0.0, download=True):
+        """download=False: the result stays on the devices (e.g. for accumulate); returns (None, low, high)."""
+        out = np.zeros(self.width * self.height, np.float32) if download else None
         cl, ch = C.c_int64(0), C.c_int64(0)
         capi.check(self._lib.nl_group_run(self._g, int(mode), C.c_float(sigma_low), C.c_float(sigma_high),
-                                          C.c_float(ref_loc), capi.fptr(out), C.byref(cl), C.byref(ch)))
+                                          C.c_float(ref_loc), capi.fptr(out) if download else None,
+                                          C.byref(cl), C.byref(ch)))
         return out, cl.value, ch.value
+
+    def upload_frame(self, idx, frame):
+        """Overlapped upload of one whole frame (nl_group_upload_frame)."""
+        f = np.ascontiguousarray(frame, dtype=np.float32).reshape(-1)
+        assert f.size == self.width * self.height
+        capi.check(self._lib.nl_group_upload_frame(self._g, int(idx), capi.fptr(f)))
 
     def find_sigmas(self, mode, clip_perc_low, clip_perc_high, ref_loc=0.0):
         out = np.zeros(self.width * self.height, np.float32)

@@ -156,3 +156,21 @@ def test_bench_self_launches_ranks_and_reports_strong_scaling():
     assert one["n_gpus"] == 1 and one["config"]["rows_per_gpu"] == 96
     assert (one["config"]["clip_low"], one["config"]["clip_high"]) == (doc["config"]["clip_low"], doc["config"]["clip_high"])
     assert one["roofline"]["timed_passes_averaged"] == 3 and one["roofline"]["kernel_ms"] > 0
+
+
+def test_eight_ranks_tile_the_headline_stack_on_one_device():
+    # rehearsal of the driver's 8-GPU run on this 1-GPU box: 8 gloo ranks share device 0, each owns 512 rows
+    # (1 GiB) of the 128 x 4096 x 4096 stack; the bench line must report the 8-way strong-scaling split and the
+    # global counters of the 1-rank run (profiles/: 6 836 157 / 13 270 993)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--share-device",
+           "--steps", "3", "--warmup", "1", "--no-cpu", "--no-also"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 8 and doc["scaling"] == "strong"
+    assert doc["config"]["frames"] == 128 and doc["config"]["image_rows"] == 4096 and doc["config"]["rows_per_gpu"] == 512
+    assert (doc["config"]["clip_low"], doc["config"]["clip_high"]) == (6836157, 13270993)
+    assert doc["roofline"]["algorithmic_bytes"] == 4.0 * 512 * 4096 * 129

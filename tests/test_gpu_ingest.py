@@ -161,3 +161,83 @@ def test_async_uploads_overlap_and_match_the_blocking_path(nl, oracle):
             assert same_values(st.download_tile(n - 1), frames[n - 1].reshape(-1)[row0 * width:(row0 + rows) * width])
     rc, want, wl, wh, _ = oracle.stack_apply(2, frames, None, 2.5, 2.5)
     assert same_values(out, want) and (tl, th) == (wl, wh)
+
+
+def test_group_ingest_fits_and_projected_through_the_pinned_ring(nl, oracle):
+    # rows F3 / F4 on the multi-GPU drop-in (nl_group_upload_frame_fits / _projected): whole-frame payloads /
+    # source frames in, every tile decodes / projects its own rows on its device, overlapped (more frames than
+    # staging slots, the host buffers are overwritten right after each call); 3 tiles on this one device
+    width, height, n = 88, 50, 10
+    sw = sh = 96
+    rng = np.random.default_rng(8)
+    ms = rng.uniform(0.9, 1.1, n).astype(np.float32)
+    os_ = rng.uniform(-20, 20, n).astype(np.float32)
+    raws = [payload(16, width * height, seed=80 + k) for k in range(n)]
+    decoded = []
+    for k in range(n):
+        rc, dec, _, _, _ = oracle.fits_decode(raws[k], 16, 1.0, 32768.0)
+        decoded.append(oracle.affine(dec, ms[k], os_[k]))
+    rc, want, wl, wh, _ = oracle.stack_apply(2, np.stack(decoded), None, 2.0, 2.0)
+    with nl.StackGroup(n, width, height, n_tiles=3, devices=[0, 0, 0]) as g:
+        scratch = np.empty(width * height * 2, np.uint8)
+        for k in range(n):
+            scratch[:] = raws[k]
+            g.upload_frame_fits(k, scratch, 16, 1.0, 32768.0, ms[k], os_[k])
+            scratch[:] = 0xAB
+        g.set_exact(True)
+        got, cl, ch = g.run(2, 2.0, 2.0)
+        for t in range(3):
+            r0, nr = g.tile_rows(t)
+            assert same_values(g.tile(t).download_tile(n - 1), decoded[n - 1][r0 * width:(r0 + nr) * width])
+    assert same_values(got, want) and (cl, ch) == (wl, wh)
+
+    srcs = [(1000 + 30 * rng.standard_normal(sw * sh)).astype(np.float32) for _ in range(n)]
+    transs = [[1, 0.012 * (k - 4), 2.0 * k - 9.5, -0.012 * (k - 4), 1, 1.5 * k - 7.25] for k in range(n)]
+    aligned = []
+    for k in range(n):
+        rc, a = oracle.project_bilinear(srcs[k], sw, sh, width, height, transs[k], np.nan)
+        assert rc == 0
+        aligned.append(oracle.affine(a, ms[k], os_[k]))
+    rc, want, wl, wh, _ = oracle.stack_apply(2, np.stack(aligned), None, 2.5, 2.5)
+    with nl.StackGroup(n, width, height, n_tiles=3, devices=[0, 0, 0]) as g:
+        scratch = np.empty(sw * sh, np.float32)
+        for k in range(n):
+            scratch[:] = srcs[k]
+            g.upload_frame_projected(k, scratch, sw, sh, transs[k], np.nan, ms[k], os_[k])
+            scratch[:] = -7.0
+        g.set_exact(True)
+        got, cl, ch = g.run(2, 2.5, 2.5)
+    assert same_values(got, want) and (cl, ch) == (wl, wh)
+    assert np.isnan(np.stack(aligned)).any()
+
+
+def test_overlapped_ingest_on_one_handle_mixes_with_plain_uploads(nl, oracle):
+    # nl_stack_upload_frame_fits_async / _projected_async / _async on the same ring, in any order
+    width, height, n = 64, 30, 9
+    row0, rows = 6, 20
+    rng = np.random.default_rng(9)
+    frames = []
+    with nl.StackHandle(n, width, height, row0=row0, rows=rows) as st:
+        for k in range(n):
+            if k % 3 == 0:
+                raw = payload(-32, width * height, seed=90 + k)
+                tile = raw[row0 * width * 4:(row0 + rows) * width * 4]
+                st.upload_frame_fits_async(k, tile, -32, 1.0, 0.0)
+                rc, dec, _, _, _ = oracle.fits_decode(raw, -32, 1.0, 0.0)
+                frames.append(dec)
+            elif k % 3 == 1:
+                src = (500 + 10 * rng.standard_normal(70 * 40)).astype(np.float32)
+                trans = [1, 0.02, 1.5 * k - 4, -0.02, 1, 0.5 * k - 3]
+                st.upload_frame_projected_async(k, src, 70, 40, trans, np.nan, 1.0, 0.0)
+                rc, a = oracle.project_bilinear(src, 70, 40, width, height, trans, np.nan)
+                frames.append(a)
+            else:
+                f = (200 + 5 * rng.standard_normal(width * height)).astype(np.float32)
+                st.upload_frame_async(k, f)
+                frames.append(f)
+        st.set_exact(True)
+        got, cl, ch = st.run(1, 0.0, 0.0)              # mean: NaN = no data
+        got = got[row0 * width:(row0 + rows) * width]
+    tiles = np.stack(frames).reshape(n, height, width)[:, row0:row0 + rows, :].reshape(n, -1)
+    rc, want, _, _, _ = oracle.stack_apply(1, np.ascontiguousarray(tiles), None, 0.0, 0.0)
+    assert same_values(got, want)

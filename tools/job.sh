@@ -1,2 +1,4 @@
-NL_FUZZ_N=497,512 NL_FUZZ_MODES=2 python tests/sweeps/fuzz_parity.py 2500 11 2>&1 | tail -4
-python tests/sweeps/fuzz_parity.py 1500 12 2>&1 | tail -3
+python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+tail -6 gpurun_out/pytest_gpu.log
+free -g | head -2
+python tools/batches_probe.py 96 32 2>&1 | grep -v amdgpu.ids | tee gpurun_out/batches_probe.txt

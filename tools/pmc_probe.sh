@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 for counters in "${groups[@]}"; do
     name=$(echo "$counters" | tr ' ' '_')
     rocprofv3 --kernel-trace --pmc $counters -d "$out/${tag}_probe_$name" -o p -- \
-        python "$repo/bench.py" --steps 2 --warmup 1 --no-cpu "$@" > /dev/null 2> "$out/${tag}_probe_$name.log"
+        python "$repo/bench.py" --steps 2 --warmup 1 --no-cpu --no-also "$@" > /dev/null 2> "$out/${tag}_probe_$name.log"
     db=$(find "$out/${tag}_probe_$name" -name 'p_results.db' | head -1)
     if [ -n "$db" ]; then python "$repo/tools/pmc_dump.py" "$db"; else tail -5 "$out/${tag}_probe_$name.log"; fi
 done

@@ -4,6 +4,7 @@
 set -u
 P=tools/gpu_profile.sh
 timeout 300 $P sigma128
+timeout 300 $P sigma128tile --height 512 --row0 1536 --image-height 4096
 timeout 300 $P sigma32 --frames 32
 timeout 300 $P sigma300 --frames 300
 timeout 300 $P sigma200 --frames 200
@@ -21,5 +22,5 @@ timeout 300 $P median512 --mode 0 --frames 512
 timeout 300 $P mad128 --mode 4
 timeout 300 $P mean128 --mode 1
 timeout 300 $P wsigma128 --weighted
-timeout 300 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 tail -c 400 gpurun_out/bench_default.json

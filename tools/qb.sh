@@ -1,7 +1,7 @@
 #!/bin/bash
 # quick bench lines (no profiler): tools/qb.sh "<bench args>" "<bench args>" ...   -> one summary line each
 for a in "$@"; do
-  python bench.py --steps 10 --warmup 3 $a 2>/dev/null | python3 -c "
+  python bench.py --steps 10 --warmup 3 --no-also $a 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     l=l.strip()

@@ -2,7 +2,7 @@
 # kernel timeline of a few passes (run on the GPU box): tools/timeline.sh <bench args>  -> gpurun_out/timeline.txt
 repo=$(pwd); out=$repo/gpurun_out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/tl && rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tl -o t -- python $repo/bench.py --steps 4 --warmup 3 --no-cpu "$@" > /dev/null 2> /tmp/tl.log
+rm -rf /tmp/tl && rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tl -o t -- python $repo/bench.py --steps 4 --warmup 3 --no-cpu --no-also "$@" > /dev/null 2> /tmp/tl.log
 f=$(find /tmp/tl -name '*kernel_trace.csv' | head -1)
 python3 - "$f" > $out/timeline.txt <<'PY'
 import csv, sys

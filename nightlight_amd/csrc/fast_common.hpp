@@ -160,9 +160,11 @@ struct FusedNet;                                               // specialisation
 // straight from memory (the column holds no NaN here, so there is nothing to quiet).  Leaving
 // them to the compiler instead lets it schedule more freely, which the MAD kernel (two sorts at
 // 168 registers) prefers.
-template <class Net, int NS, bool ASM = true>
-__device__ __forceinline__ void run_network(float (&v)[NS])
+// (NA: the array may be longer than the network -- the network then orders v[0 .. NS) and leaves the rest)
+template <class Net, int NS, bool ASM = true, int NA = NS>
+__device__ __forceinline__ void run_network(float (&v)[NA])
 {
+    static_assert(NS <= NA, "network larger than the column");
     float w[Net::kSlots];
     static_range<0, NS>([&](auto K) NL_INL { w[decltype(K)::value] = v[decltype(K)::value]; });
     static_chunks<0, Net::kCount, 128>([&](auto I) NL_INL {
@@ -182,12 +184,12 @@ __device__ __forceinline__ void run_network(float (&v)[NS])
     static_range<0, NS>([&](auto K) NL_INL { v[decltype(K)::value] = w[Net::kOut[decltype(K)::value]]; });
 }
 
-template <int NS, bool ASM = true>
-__device__ __forceinline__ void sort_network(float (&v)[NS])
+template <int NS, bool ASM = true, int NA = NS>
+__device__ __forceinline__ void sort_network(float (&v)[NA])
 {
     using Net = FusedNet<NS, 0, 0, 0, 0>;
     static_assert(Net::kComparators == OemNetwork<NS>::kCount, "sort_tables.inc does not match OemNetwork");
-    run_network<Net, NS, ASM>(v);
+    run_network<Net, NS, ASM, NA>(v);
 }
 
 // The zonal kernels need exact ranks only at the ends (clip zones) and around

@@ -153,10 +153,13 @@ __device__ __forceinline__ float pick_rank(const float (&v)[NS], int g, int role
 // Sort every lane's column and merge the LPP runs of a pixel: afterwards lane r holds the global
 // ranks [r*NS, r*NS+NS).  ENDS_ONLY: the last merge orders only the KEEP lowest / highest ranks
 // of every lane (see half_clean_ends).
-template <int LPP, int NS, bool ENDS_ONLY, int KEEP = 16, int CH = 32>
+// NSL: positions [NSL, NS) of every lane are known to hold +Inf (frames the stack does not have: the caller's
+// frame-count class), so the in-lane sort is the network of NSL positions -- 1 100 instead of 2 184 operations
+// for a 300-frame stack on four lanes
+template <int LPP, int NS, bool ENDS_ONLY, int KEEP = 16, int CH = 32, int NSL = NS>
 __device__ __forceinline__ void ml_sort_merge(float (&v)[NS], int role)
 {
-    sort_network<NS>(v);
+    sort_network<NSL, true, NS>(v);
     // ---- merge the LPP sorted runs: lane r ends up with ranks [r*NS, r*NS+NS) ----
     // (zonal: the final half-cleaners only order the ends of each lane, see half_clean_ends)
     static_assert(kZone + kPadMax <= KEEP, "zones must lie inside the sorted ends");
@@ -245,12 +248,12 @@ int nan_cnt = 0;
     return quad_sum<LPP>(NS - nan_cnt);
 }
 
-template <int LPP, int NS, bool ENDS_ONLY, int KEEP = 16, int CH = 32>
+template <int LPP, int NS, bool ENDS_ONLY, int KEEP = 16, int CH = 32, int NSL = NS>
 __device__ __forceinline__ int ml_gather_sorted(const float *frames, int64_t stride, int N, bool on, int64_t pix,
                                                 int role, float (&v)[NS])
 {
     const int n = ml_gather_raw<LPP, NS>(frames, stride, N, on, pix, role, v);
-    ml_sort_merge<LPP, NS, ENDS_ONLY, KEEP, CH>(v, role);
+    ml_sort_merge<LPP, NS, ENDS_ONLY, KEEP, CH, NSL>(v, role);
     return n;
 }
 

@@ -56,6 +56,9 @@ template <int LPP, bool WINSOR, int NTOP>
 struct MlzLayout {
     static constexpr int NS = kMlNS, NT = NS * LPP;
     static constexpr bool FULL = NTOP == NT;                    // the columns sit at the ends of lanes
+    // a lane is dealt at most NTOP / LPP frames: its positions from there on hold +Inf, the in-lane sort is the
+    // network of the next tabulated size (sort_tables.inc: 80, 96, 112, 128)
+    static constexpr int NSL = NTOP / LPP <= 80 ? 80 : (NTOP / LPP <= 96 ? 96 : (NTOP / LPP <= 112 ? 112 : 128));
     static constexpr int BLOCK = mlz_block<LPP>;
     static constexpr int PW = BLOCK / LPP;                      // pixels per workgroup = LDS row length (64)
     // alive window: a < ZLC, b > NTOP - ZHC; up to PADS missing samples (frames short of NTOP + NaNs)
@@ -298,7 +301,7 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         n = ml_gather_raw<LPP, NS>(p.frames, p.stride, N, on, pix, role, v);
         sort_network<NS>(v);                               // the lanes' runs are not merged: select_ends / select_window
     } else {
-        n = ml_gather_sorted<LPP, NS, L::FULL && !WINSOR, 32>(p.frames, p.stride, N, on, pix, role, v);
+        n = ml_gather_sorted<LPP, NS, L::FULL && !WINSOR, 32, 32, L::NSL>(p.frames, p.stride, N, on, pix, role, v);
     }
 
     // ---- columns and median window to LDS ----

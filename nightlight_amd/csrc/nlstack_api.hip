@@ -748,7 +748,13 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
             grid0 = want < 1024 ? 1024 : (want > kCoopGrid ? kCoopGrid : want);
             grid1 = grid0 / 4 < 512 ? 512 : grid0 / 4;
         }
-        struct Fork { nl_stack *h; nl::StackArgs e; int mode; unsigned *snap; int grid0; hipError_t err; } fork{h, e, mode, snap, grid0, hipSuccess};
+        // NL_COOP4=1 (developer switch): replay the lists four pixels per wave (stack_exact_coop4.hip).  Its
+        // sequential sums cost a third of the instructions, but with a quarter of the waves in flight the replay
+        // turns latency-bound: C3 tile 5.32 -> 6.74 ms, sigma 512 tail 0.82 -> 1.45 ms -- measured, off by default
+        static const bool coop4_env = [] { const char *e = getenv("NL_COOP4"); return e && e[0] == '1'; }();
+        const bool coop4 = coop && coop4_env && nl::coop4_supported(mode, weighted, a.n_frames) != 0;
+        if (coop4) { grid0 = (grid0 + 3) / 4; grid1 = (grid1 + 3) / 4; }
+        struct Fork { nl_stack *h; nl::StackArgs e; int mode; unsigned *snap; int grid0; bool coop4; hipError_t err; } fork{h, e, mode, snap, grid0, coop4, hipSuccess};
         nl::AfterDominant after = nullptr;
         if (coop) after = [](void *u) {
             Fork *k = static_cast<Fork *>(u);
@@ -759,7 +765,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
                 nl::StackArgs first = k->e;
                 first.list_snap = k->snap;
                 first.list_part = 0;
-                if (err == hipSuccess) err = nl::launch_stack_sigma_coop(k->mode, first, k->grid0, hh->stream, &ignored);
+                if (err == hipSuccess) err = k->coop4 ? nl::launch_stack_sigma_coop4(k->mode, first, k->grid0, hh->stream, &ignored)
+                                                      : nl::launch_stack_sigma_coop(k->mode, first, k->grid0, hh->stream, &ignored);
                 if (err == hipSuccess) err = hipEventRecord(hh->ev_join, hh->stream);
                 k->err = err;
                 return;
@@ -768,7 +775,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
             nl::StackArgs first = k->e;
             first.list_snap = k->snap;                    // the list as the dominant kernel left it (snapshot on the device)
             first.list_part = 0;
-            if (err == hipSuccess) err = nl::launch_stack_sigma_coop(k->mode, first, k->grid0, hh->side_stream, &ignored);
+            if (err == hipSuccess) err = k->coop4 ? nl::launch_stack_sigma_coop4(k->mode, first, k->grid0, hh->side_stream, &ignored)
+                                                  : nl::launch_stack_sigma_coop(k->mode, first, k->grid0, hh->side_stream, &ignored);
             if (err == hipSuccess) err = hipEventRecord(hh->ev_join, hh->side_stream);
             k->err = err;
         };
@@ -783,7 +791,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         if (coop) {
             e.list_snap = snap;                           // the generic pass's additions
             e.list_part = 1;
-            NL_HIP(nl::launch_stack_sigma_coop(mode, e, grid1, h->stream, &exact_name));
+            if (coop4) NL_HIP(nl::launch_stack_sigma_coop4(mode, e, grid1, h->stream, &exact_name));
+            else       NL_HIP(nl::launch_stack_sigma_coop(mode, e, grid1, h->stream, &exact_name));
             NL_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         } else {
             int lanes = 0;
@@ -811,6 +820,14 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         const int64_t tiles = (a.npix + 63) / 64;
         const int64_t g = tiles < (1 << 20) ? tiles : (1 << 20);
         NL_HIP(nl::launch_stack_sigma_tile(mode, a, (int)g, h->stream, &h->last_kernel));
+        NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
+        NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
+        h->last_has_counters = true;
+    } else if (h->exact_flavour == 4 && nl::coop4_supported(mode, weighted, a.n_frames)) {
+        // nl_stack_set_exact(h, 4): the four-pixels-per-wave replay over the whole tile (verification)
+        h->last_used_fast = false;
+        const int64_t g = (a.npix + 3) / 4 < 65536 ? (a.npix + 3) / 4 : 65536;
+        NL_HIP(nl::launch_stack_sigma_coop4(mode, a, (int)g, h->stream, &h->last_kernel));
         NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
         NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
         h->last_has_counters = true;

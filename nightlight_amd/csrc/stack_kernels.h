@@ -198,6 +198,11 @@ int coop_supported(int mode, bool weighted, int n_frames);
 hipError_t launch_stack_median_coop(const StackArgs &args, int grid, hipStream_t stream, const char **name);
 hipError_t launch_stack_sigma_coop(int mode, const StackArgs &args, int grid, hipStream_t stream, const char **name);
 
+// ---- stack_exact_coop4.hip (the same replay, four pixels per wave on 16-lane rows: the sequential sums cost a
+// third of the instructions per pixel) ----
+int coop4_supported(int mode, bool weighted, int n_frames);
+hipError_t launch_stack_sigma_coop4(int mode, const StackArgs &args, int grid, hipStream_t stream, const char **name);
+
 // ---- stack_exact_tile.hip (bit-exact sigma / winsorized clipping over whole tiles: one wave = 64
 // consecutive pixels, columns in LDS, one pixel per lane; the weighted modes' default path) ----
 constexpr int kTileMaxFramesDefault = 64;      // frame counts up to which it beats the wave-per-pixel replay

@@ -206,6 +206,22 @@ def test_wave_per_pixel_exact_replay_is_bit_exact(nl, oracle, n):
                 assert gc == wc
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 15, 16, 17, 33, 64, 65, 128, 130, 300, 512])
+def test_four_pixels_per_wave_exact_replay_is_bit_exact(nl, oracle, n):
+    # stack_exact_coop4.hip: the same replay with four pixels per wave on 16-lane rows (row_shr chains); forced
+    # for every pixel (37 x 5 = 185 pixels: the last wave holds one pixel, rows with different sample counts,
+    # NaN borders, ties)
+    width, height = 37, 5
+    frames = make_frames(n, width, height, seed=1900 + n, ties=(n % 2 == 1))
+    weights = np.random.default_rng(n).uniform(0.2, 1.0, n).astype(np.float32)
+    for mode in (2, 3):
+        for kappa in (2.75, 1.0):
+            for w in (None, weights):
+                got, gc, want, wc = run_both(nl, oracle, mode, frames, width, height, w, kappa, kappa, exact=4)
+                assert same_values(got, want), "coop4 %s n=%d: %s" % (MODES[mode], n, describe_mismatch(got, want))
+                assert gc == wc
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 9, 25, 31, 33, 64, 65, 100, 128])
 def test_register_resident_linear_fit_is_bit_exact(nl, oracle, n):
     # default dispatch for linear fit (stack_linfit.hip): one sort, then every sum

@@ -1,11 +1,9 @@
-python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "four_pixels or wave_per_pixel" 2>&1 | tail -15
-python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
-tail -6 gpurun_out/pytest_gpu.log
-for c4 in 0 1; do
-export NL_COOP4=$c4; echo "== NL_COOP4=$c4"
-python tools/ab_flags.py 3 512 512 1536 4096 2 0
-python tools/ab_flags.py 2 512 4096 0 4096 2 0
-python tools/ab_flags.py 2 128 512 1536 4096 3 0
-python tools/ab_flags.py 3 128 4096 0 4096 2 0
-python tools/ab_flags.py 2 128 4096 0 4096 2 0
-done
+P=tools/gpu_profile.sh
+timeout 300 $P sigma300 --frames 300 > /dev/null 2>&1
+timeout 300 $P sigma200 --frames 200 > /dev/null 2>&1
+timeout 300 $P sigma256 --frames 256 > /dev/null 2>&1
+timeout 300 $P winsor300tile --mode 3 --frames 300 --height 1024 > /dev/null 2>&1
+timeout 300 $P sigma384 --frames 384 > /dev/null 2>&1
+python tests/sweeps/parity_sweep.py > gpurun_out/parity_sweep.txt 2>&1; tail -2 gpurun_out/parity_sweep.txt
+python tests/sweeps/fuzz_parity.py 60000 31 > gpurun_out/fuzz_a.txt 2>&1; tail -2 gpurun_out/fuzz_a.txt
+NL_FUZZ_N=129,512 NL_FUZZ_MODES=2,3 python tests/sweeps/fuzz_parity.py 20000 32 > gpurun_out/fuzz_b.txt 2>&1; tail -2 gpurun_out/fuzz_b.txt

@@ -190,7 +190,13 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
         const int64_t snap = min((int64_t)(s - 1u), limit);
         if (p.list_part == 0) limit = snap; else first = snap;
     }
-    for (int64_t item = first + blockIdx.x; item < limit; item += gridDim.x) {
+    // Whole-tile replays (no list): a pixel's sample is 4 bytes of a 128-byte line that 31 neighbours share.
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so with pixel = workgroup index the
+    // neighbours sit on other XCDs and every line is fetched again and again (29.6 x the algorithmic bytes,
+    // measured).  XCD x takes the x-th eighth of every sweep instead: neighbours run side by side under one L2.
+    int64_t wg = blockIdx.x;
+    if (!p.list && (gridDim.x & 7u) == 0u) wg = (int64_t)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    for (int64_t item = first + wg; item < limit; item += gridDim.x) {
         const int64_t pix = p.list ? (int64_t)p.list[item] : item;
         const float *fr = p.frames + pix;
         lds_fence();
@@ -316,7 +322,9 @@ __global__ __launch_bounds__(64) void stack_median_coop_kernel(StackArgs p)
     unsigned short *rfwd = lpos + p.n_frames;
     const int lane = threadIdx.x;
     const int N = p.n_frames;
-    for (int64_t pix = blockIdx.x; pix < p.npix; pix += gridDim.x) {
+    int64_t wg = blockIdx.x;                       // XCD-contiguous pixels, see stack_sigma_coop_kernel
+    if ((gridDim.x & 7u) == 0u) wg = (int64_t)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    for (int64_t pix = wg; pix < p.npix; pix += gridDim.x) {
         const float *fr = p.frames + pix;
         lds_fence();
         int n = 0;

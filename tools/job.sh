@@ -1,9 +1,2 @@
-P=tools/gpu_profile.sh
-timeout 300 $P sigma300 --frames 300 > /dev/null 2>&1
-timeout 300 $P sigma200 --frames 200 > /dev/null 2>&1
-timeout 300 $P sigma256 --frames 256 > /dev/null 2>&1
-timeout 300 $P winsor300tile --mode 3 --frames 300 --height 1024 > /dev/null 2>&1
-timeout 300 $P sigma384 --frames 384 > /dev/null 2>&1
-python tests/sweeps/parity_sweep.py > gpurun_out/parity_sweep.txt 2>&1; tail -2 gpurun_out/parity_sweep.txt
-python tests/sweeps/fuzz_parity.py 60000 31 > gpurun_out/fuzz_a.txt 2>&1; tail -2 gpurun_out/fuzz_a.txt
-NL_FUZZ_N=129,512 NL_FUZZ_MODES=2,3 python tests/sweeps/fuzz_parity.py 20000 32 > gpurun_out/fuzz_b.txt 2>&1; tail -2 gpurun_out/fuzz_b.txt
+bash tools/qb.sh "--weighted --no-cpu" "--weighted --mode 3 --no-cpu --height 1024" "--frames 600 --height 256 --no-cpu" "--frames 600 --mode 0 --height 256 --no-cpu"
+python -m pytest tests -m gpu -x -q -k "wave_per_pixel or weighted or more_than_512 or large_stacks" 2>&1 | tail -3

@@ -13,6 +13,17 @@ constexpr float kU = 5.9604644775390625e-8f;   // 2^-24, fp32 unit roundoff
 constexpr int kZone = 8;      // sorted positions per side that may be clipped in the zonal path
 constexpr int kPadMax = 8;    // missing samples (NaN) a lane may have in the zonal path
 constexpr unsigned kGenericGrid = 2048;   // workgroups of the generic pass over the hand-over list
+// The list's length is only known on the device, so the generic pass is a fixed grid with a grid-stride loop --
+// but thousands of empty workgroups (48 KiB of LDS each in the LDS generic pass: three per CU) take longer to
+// drain than a short list takes to process.  The length the last finished pass reported sizes the grid: half
+// as many workgroups again as it needed, at least 64.
+inline unsigned generic_grid(unsigned hint, unsigned pixels_per_wg, unsigned max_grid)
+{
+    if (hint == 0) return max_grid;
+    const unsigned need = (hint - 1 + pixels_per_wg - 1) / pixels_per_wg;
+    const unsigned g = need + need / 2 + 64;
+    return g < max_grid ? g : max_grid;
+}
 
 // A generic pass appends to the exact-replay list while the first replay may already be reading it:
 // before its first append every workgroup makes sure the list's length as the dominant kernel left it

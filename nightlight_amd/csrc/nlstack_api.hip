@@ -94,6 +94,7 @@ struct nl_stack {
     bool sets_clean = false;                   // both sets as a fused pass leaves them: the current one used, the other zeroed
     unsigned long long *d_partial = nullptr;   // [kClipSlots][2] clip accumulators + 2 words of list lengths
     unsigned fb_hint = 0;                      // exact-list length of the last finished fast pass + 1 (0 = unknown)
+    unsigned gen_hint = 0;                     // same for the generic list
     bool last_fused = false;
     bool last_lists = false;                   // the last pass left its list lengths behind the totals (d_counters[2])
     unsigned dev_flags = 0;                    // nl_stack_set_dev_flags (A/B measurements)
@@ -726,6 +727,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         f.gen_list = h->d_gen_list;
         f.gen_count = h->d_fb_count + 1;
         f.gen_capacity = (unsigned)h->npix;
+        f.gen_hint = h->gen_hint;
         f.in_list = nullptr;
         f.in_count = nullptr;
         f.in_capacity = 0;
@@ -879,7 +881,10 @@ int nl_stack_finish(nl_stack_t *h, float *out_host, int64_t *clip_low, int64_t *
                               (size_t)h->npix * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     NL_HIP(hipStreamSynchronize(h->stream));
     h->pending = false;
-    if (h->last_has_counters && h->last_lists) h->fb_hint = (unsigned)(c[2] & 0xffffffffull) + 1u;
+    if (h->last_has_counters && h->last_lists) {
+        h->fb_hint = (unsigned)(c[2] & 0xffffffffull) + 1u;
+        h->gen_hint = (unsigned)(c[2] >> 32) + 1u;
+    }
     if (clip_low) *clip_low = (int64_t)c[0];
     if (clip_high) *clip_high = (int64_t)c[1];
     return NL_OK;

@@ -949,12 +949,12 @@ static hipError_t launch_pair(const StackArgs &args, const FastArgs &fargs, unsi
         f.in_list = fargs.gen_list;
         f.in_count = fargs.gen_count;
         f.in_capacity = fargs.gen_capacity;
-        const unsigned gblocks = tile_blocks < kGenericGrid ? tile_blocks : kGenericGrid;
+        const unsigned gblocks = generic_grid(fargs.gen_hint, 256, tile_blocks < kGenericGrid ? tile_blocks : kGenericGrid);
         if constexpr (NS > 64) {
             // whole columns + prefix sums in LDS (stack_fast_mlg.hip): a clipping or winsorization round
             // is a few LDS reads instead of a pass over 128 masked registers -- this pass is pure
             // latency (a few hundred waves at most), and it sits on every pass's critical path
-            const unsigned lblocks = 4 * tile_blocks < 4 * kGenericGrid ? 4 * tile_blocks : 4 * kGenericGrid;
+            const unsigned lblocks = generic_grid(fargs.gen_hint, 64, 4 * tile_blocks < 4 * kGenericGrid ? 4 * tile_blocks : 4 * kGenericGrid);
             keep_first(err, launch_stack_sigma_mlg(args, f, lblocks, stream, WINSOR));
         } else {
             hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false, WINSOR, false>), dim3(gblocks), dim3(256), 0,

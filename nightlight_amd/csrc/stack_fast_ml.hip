@@ -623,7 +623,7 @@ static hipError_t launch_ml(const StackArgs &args, const FastArgs &fargs, hipStr
     // switch) keeps the register version, which masks every position of every lane in every round
     static const bool mlg_on = [] { const char *e = getenv("NL_MLG"); return !(e && e[0] == '0'); }();
     if (mlg_on) {
-        keep_first(err, launch_stack_sigma_mlg(args, f, 4 * kGenericGrid, stream, WINSOR));
+        keep_first(err, launch_stack_sigma_mlg(args, f, generic_grid(fargs.gen_hint, 64 / LPP, 4 * kGenericGrid), stream, WINSOR));
         return err;
     }
     const unsigned gblocks = tile_blocks < kGenericGrid ? tile_blocks : kGenericGrid;

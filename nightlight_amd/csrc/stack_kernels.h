@@ -60,6 +60,7 @@ struct FastArgs {
     unsigned *gen_list;           // [gen_capacity] pixels a zonal wave hands to the generic pass
     unsigned *gen_count;          // device counter, zeroed before every pass
     unsigned gen_capacity;
+    unsigned gen_hint;            // 1 + the generic list's length in the last finished pass (0 = unknown): sizes the generic grid
     const unsigned *in_list;      // generic pass: list to process (nullptr = the whole tile)
     const unsigned *in_count;
     unsigned in_capacity;

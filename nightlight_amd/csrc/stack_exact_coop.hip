@@ -64,6 +64,59 @@ __device__ __forceinline__ float seq_sum(int n, F &&elem)
     return s;
 }
 
+// The partition passes of a select whose range [left, right] has shrunk to at most 63 elements, in REGISTERS:
+// lane i holds a[left + i]; a pass is two ballots, the candidate tables through ds_permute (lane t receives the
+// position of the t-th candidate from the left / from the right; lanes that have nothing to send aim at lane 63,
+// which holds no element) and the swaps through ds_bpermute / ds_permute -- no LDS traffic, no barrier.  Same
+// swaps, same pointers as coop_select below (k is 1-based inside [left, right]); the range is written back at
+// the end.  About a third of the latency of the LDS form per pass, and most passes of a select are this small.
+__device__ float coop_select_small(float *a, int left, int right, int k)
+{
+    const int lane = threadIdx.x;
+    int lo = 0, hi = right - left;
+    const bool mine = lane <= hi;
+    float x = mine ? a[left + lane] : 0.0f;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    constexpr int kTrash = 63 * 4;
+    while (lo < hi) {
+        const int pm = (lo + hi) >> 1;                       // (left + right) >> 1, relative to left
+        const float pivot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), pm));
+        const bool in = lane >= lo && lane <= hi;
+        const bool isl = in && x >= pivot;
+        const bool isr = in && x <= pivot;
+        const unsigned long long ml = __ballot(isl), mr = __ballot(isr);
+        const int nl = __popcll(ml), nr = __popcll(mr);
+        const int rl = __popcll(ml & below);                 // rank among the candidates from the left
+        const int rr = __popcll((mr >> 1) >> lane);          // rank among the candidates from the right
+        const int lt = __builtin_amdgcn_ds_permute(isl ? rl * 4 : kTrash, lane);     // lane t: L_t
+        const int rt = __builtin_amdgcn_ds_permute(isr ? rr * 4 : kTrash, lane);     // lane t: R_t
+        const int pairs = min(nl, nr);
+        const bool ok = lane < pairs && lt < rt;             // monotone in the lane
+        const int s_cnt = __popcll(__ballot(ok));
+        const bool sw = lane < s_cnt;
+        const int xl = __builtin_amdgcn_ds_bpermute(lt * 4, __float_as_int(x));
+        const int xr = __builtin_amdgcn_ds_bpermute(rt * 4, __float_as_int(x));
+        const int to_l = __builtin_amdgcn_ds_permute(sw ? lt * 4 : kTrash, xr);      // position L_t receives a[R_t]
+        const int to_r = __builtin_amdgcn_ds_permute(sw ? rt * 4 : kTrash, xl);
+        if (isl && rl < s_cnt) x = __int_as_float(to_l);     // (no position is both: see coop_select)
+        else if (isr && rr < s_cnt) x = __int_as_float(to_r);
+        const int r_next = s_cnt < nr ? __builtin_amdgcn_readlane(rt, s_cnt) : -1;
+        const int l_prev = s_cnt > 0 ? __builtin_amdgcn_readlane(lt, s_cnt - 1) : -1;
+        const int r = max(r_next, l_prev);
+        const int offset = r - lo + 1;
+        if (k <= offset) {
+            hi = r;
+        } else {
+            lo = r + 1;
+            k -= offset;
+        }
+    }
+    if (mine) a[left + lane] = x;
+    const float res = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lo));
+    lds_fence();
+    return res;
+}
+
 // qsort.go:94-126 on a[0..n), k 1-based; all control values are wave-uniform.
 //
 // One Hoare partition pass (qsort.go:100-114) done by the whole wave at once.
@@ -84,6 +137,7 @@ __device__ float coop_select(float *a, unsigned short *lpos, unsigned short *rfw
     const unsigned long long below = (1ull << lane) - 1ull;
     int left = 0, right = n - 1;
     while (left < right) {
+        if (right - left < 63) return coop_select_small(a, left, right, k);
         const float pivot = a[(left + right) >> 1];
         // classify, and list the misplaced positions in scan order
         int nl = 0, nr = 0;

@@ -810,7 +810,9 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         h->last_fused = fused;
         h->last_has_counters = true;
         h->last_used_fast = true;
-    } else if ((h->exact_flavour == 3 || (!h->force_exact && weighted && a.n_frames <= nl::kTileMaxFramesDefault)) &&
+    } else if ((h->exact_flavour == 3 ||
+                (!h->force_exact && weighted &&
+                 a.n_frames <= (mode == NL_ST_WINSOR_SIGMA ? nl::kTileMaxFramesWinsor : nl::kTileMaxFramesSigma))) &&
                nl::tile_supported(mode, weighted, a.n_frames)) {
         // bit-exact replay over the whole tile, 64 consecutive pixels per wave with their columns in
         // LDS, one pixel per lane: the default for weighted sigma / winsorized clipping (their result
@@ -825,8 +827,13 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
         NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
         h->last_has_counters = true;
-    } else if (h->exact_flavour == 4 && nl::coop4_supported(mode, weighted, a.n_frames)) {
-        // nl_stack_set_exact(h, 4): the four-pixels-per-wave replay over the whole tile (verification)
+    } else if ((h->exact_flavour == 4 ||
+                (!h->force_exact && weighted && a.n_frames <= 512 &&
+                 (mode == NL_ST_WINSOR_SIGMA || a.n_frames <= nl::kCoop4MaxFramesSigma))) &&
+               nl::coop4_supported(mode, weighted, a.n_frames)) {
+        // the four-pixels-per-wave replay over the whole tile: weighted stacks of medium depth (the sequential sums
+        // are a large share of a dense replay, and a row of 16 lanes wastes fewer of them on short ranges);
+        // nl_stack_set_exact(h, 4) forces it (verification)
         h->last_used_fast = false;
         const int64_t g = (a.npix + 3) / 4 < 65536 ? (a.npix + 3) / 4 : 65536;
         NL_HIP(nl::launch_stack_sigma_coop4(mode, a, (int)g, h->stream, &h->last_kernel));

@@ -11,11 +11,13 @@
 // registers; every loop runs until no row needs it any more, rows that are done are predicated off, and the
 // LDS fences sit outside all predicates.
 //
-// MEASURED: bit-exact (tests/test_gpu_parity.py, nl_stack_set_exact(h, 4)), but SLOWER than one pixel per wave
-// as the replay engine of the hand-over lists -- a quarter of the waves are in flight (the same LDS per pixel,
-// four pixels per wave), every loop runs for the slowest of four rows, and the replay turns latency-bound:
-// C3 tile 5.32 -> 6.74 ms, sigma 512 tail 0.82 -> 1.45 ms.  Kept as a verification flavour (and behind
-// NL_COOP4=1 for A/B runs), not dispatched by default.
+// MEASURED: bit-exact (tests/test_gpu_parity.py, nl_stack_set_exact(h, 4)).  As the replay engine of the
+// hand-over LISTS it is slower than one pixel per wave -- a quarter of the waves are in flight (the same LDS per
+// pixel, four pixels per wave), every loop runs for the slowest of four rows, and that replay is latency-bound:
+// C3 tile 5.32 -> 6.74 ms, sigma 512 tail 0.82 -> 1.45 ms (NL_COOP4=1 switches it on for A/B runs).  Over WHOLE
+// tiles (weighted stacks), where the replay is bound by instruction issue, it wins from about 45 frames on:
+// winsorized 96 frames 15.8 -> 9.8 ms per 512 x 4096 pixels, sigma 96 frames 5.47 -> 4.32 ms
+// (tools/replay_probe2.py): dispatched there (nlstack_api.hip, stack_kernels.h).
 //
 // The algorithm, the visiting orders and hence every output bit and both counters are those of
 // stack_exact_coop.hip (qsort.go:94-126, stats.go:246-261, stack.go:372-436, 442-531, 611-705, 710-829).
@@ -205,7 +207,10 @@ __global__ __launch_bounds__(64) void stack_sigma_coop4_kernel(StackArgs p)
     }
     int c_lo = 0, c_hi = 0;                                    // row-uniform
 
-    for (int64_t item0 = first + 4 * (int64_t)blockIdx.x; item0 < limit; item0 += 4 * (int64_t)gridDim.x) {
+    // whole-tile replays: XCD-contiguous pixels (see stack_sigma_coop_kernel)
+    int64_t wg = blockIdx.x;
+    if (!p.list && (gridDim.x & 7u) == 0u) wg = (int64_t)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    for (int64_t item0 = first + 4 * wg; item0 < limit; item0 += 4 * (int64_t)gridDim.x) {
         const int64_t item = item0 + row;
         const bool on = item < limit;
         int64_t pix = 0;

@@ -206,7 +206,14 @@ hipError_t launch_stack_sigma_coop4(int mode, const StackArgs &args, int grid, h
 
 // ---- stack_exact_tile.hip (bit-exact sigma / winsorized clipping over whole tiles: one wave = 64
 // consecutive pixels, columns in LDS, one pixel per lane; the weighted modes' default path) ----
-constexpr int kTileMaxFramesDefault = 64;      // frame counts up to which it beats the wave-per-pixel replay
+// frame counts up to which it beats the other replays over a whole tile (tools/replay_probe2.py, weighted stacks,
+// ms per 512 x 4096 pixels, tile / four pixels per wave / one pixel per wave -- sigma: 40 frames 1.54 / 2.16 / 2.79,
+// 56 frames 2.82 / 2.84 / 3.17, 64 frames 3.5 / 2.9 / 3.2; winsorized: 40 frames 4.37 / 5.22 / 8.11, 48 frames
+// 5.34 / 5.28 / 8.25, 56 frames 6.70 / 6.27 / 8.54)
+constexpr int kTileMaxFramesSigma = 56, kTileMaxFramesWinsor = 44;
+// beyond that: four pixels per wave (stack_exact_coop4.hip) up to here -- 96 frames: sigma 4.32 vs 5.47, winsorized
+// 9.80 vs 15.8 -- and one pixel per wave above (sigma at 128 frames: 5.96 vs 6.15; winsorized stays: 15.1 vs 16.7)
+constexpr int kCoop4MaxFramesSigma = 120;
 int tile_supported(int mode, bool weighted, int n_frames);
 hipError_t launch_stack_sigma_tile(int mode, const StackArgs &args, int grid, hipStream_t stream, const char **name);
 

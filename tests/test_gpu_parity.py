@@ -317,14 +317,17 @@ def test_tile_replay_heavy_clipping_and_degenerate_bounds(nl, oracle):
 
 
 def test_weighted_clip_modes_default_dispatch(nl):
-    # up to 64 frames the tile kernel, above it the wave-per-pixel replay (faster there)
-    for n, prefix in ((16, "stack_sigma_tile_kernel<"), (64, "stack_sigma_tile_kernel<"), (65, "stack_sigma_coop_kernel<")):
+    # each depth runs the replay engine that measured fastest over a whole tile (stack_kernels.h): 64 pixels per
+    # wave, then four pixels per wave, then (sigma) one pixel per wave
+    tile, four, one = "stack_sigma_tile_kernel<", "stack_sigma_coop4_kernel<", "stack_sigma_coop_kernel<"
+    for n, sigma, winsor in ((16, tile, tile), (44, tile, tile), (45, tile, four), (56, tile, four), (57, four, four),
+                             (96, four, four), (120, four, four), (128, one, four), (300, one, four)):
         with nl.StackHandle(n, 64, 4) as st:
             st.fill_synthetic(1)
             st.set_weights(np.linspace(0.2, 1.0, n).astype(np.float32))
-            for mode in (2, 3):
+            for mode, prefix in ((2, sigma), (3, winsor)):
                 st.run(mode, 2.0, 2.0)
-                assert st.last_kernel_name.startswith(prefix), st.last_kernel_name
+                assert st.last_kernel_name.startswith(prefix), (n, mode, st.last_kernel_name)
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3])

@@ -170,7 +170,8 @@ int nl_stack_set_exact(nl_stack_t *h, int on);
 /* Developer switches of the sigma / winsorized fast path, for A/B timing inside one process (results are the
  * same either way): bit 0 = plain pass protocol (memset before, reduction kernel after every pass) instead of
  * the fused one, bit 1 = the exact replay of the dominant kernel's hand-overs runs in front of the generic pass
- * on the same stream instead of beside it (kernel traces then show each kernel's own duration).  Default 0.
+ * on the same stream instead of beside it (kernel traces then show each kernel's own duration), bit 2 = weighted
+ * stacks replay every clipping round in full (no decision pass).  Default 0.
  * No counterpart in the reference. */
 int nl_stack_set_dev_flags(nl_stack_t *h, unsigned flags);
 /* Pixels of the last pass that were re-done by the exact kernel. */

@@ -93,6 +93,9 @@ struct nl_stack {
     int cur_set = 0;
     bool sets_clean = false;                   // both sets as a fused pass leaves them: the current one used, the other zeroed
     unsigned long long *d_partial = nullptr;   // [kClipSlots][2] clip accumulators + 2 words of list lengths
+    float2 *d_bounds = nullptr;                // decision pass of weighted stacks: [kBoundRounds][npix] thresholds, lazily allocated
+    unsigned char *d_nrounds = nullptr;        // [npix]
+    bool bounds_tried = false;
     unsigned fb_hint = 0;                      // exact-list length of the last finished fast pass + 1 (0 = unknown)
     unsigned gen_hint = 0;                     // same for the generic list
     bool last_fused = false;
@@ -160,6 +163,8 @@ static int destroy_impl(nl_stack_t *h)
     if (h->d_weights) (void)hipFree(h->d_weights);
     if (h->d_xstat) (void)hipFree(h->d_xstat);
     if (h->d_sets) (void)hipFree(h->d_sets);
+    if (h->d_bounds) (void)hipFree(h->d_bounds);
+    if (h->d_nrounds) (void)hipFree(h->d_nrounds);
     if (h->d_fb_list) (void)hipFree(h->d_fb_list);
     if (h->d_gen_list) (void)hipFree(h->d_gen_list);
     if (h->d_counters) (void)hipFree(h->d_counters);
@@ -532,6 +537,24 @@ static const nl::LinfitCascade *linfit_cascade(nl_stack_t *h, int lanes_per_pixe
     return out;
 }
 
+// Weighted sigma / winsorized stacks of 45 .. 128 frames run a decision pass in front of the bit-exact replay
+// (stack_fast_decide.hip): scratch for its thresholds.  false: off (NL_WDECIDE=0, allocation failed).
+static bool ensure_bounds(nl_stack *h)
+{
+    static const bool on = [] { const char *e = getenv("NL_WDECIDE"); return !(e && e[0] == '0'); }();
+    if (!on || (h->dev_flags & 4u)) return false;
+    if (h->d_bounds) return true;
+    if (h->bounds_tried) return false;
+    h->bounds_tried = true;
+    if (hipMalloc(&h->d_bounds, (size_t)nl::kBoundRounds * (size_t)h->npix * sizeof(float2)) != hipSuccess ||
+        hipMalloc(&h->d_nrounds, (size_t)h->npix) != hipSuccess) {
+        (void)hipGetLastError();
+        if (h->d_bounds) { (void)hipFree(h->d_bounds); h->d_bounds = nullptr; }
+        return false;
+    }
+    return true;
+}
+
 static int auto_select_mode(int l)   // stack.go:45-55
 {
     if (l >= 25) return NL_ST_LINEAR_FIT;
@@ -576,6 +599,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
     a.list_part = 0;
     a.final = nullptr;
     a.zero_next = nullptr;
+    a.bounds = nullptr;
+    a.nrounds = nullptr;
 
     {
         const int slot = (int)(h->pass_seq % kTimingRing);
@@ -835,6 +860,13 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         // are a large share of a dense replay, and a row of 16 lanes wastes fewer of them on short ranges);
         // nl_stack_set_exact(h, 4) forces it (verification)
         h->last_used_fast = false;
+        if (weighted && h->exact_flavour == 0 && nl::decide_supported(mode, a.n_frames, a.npix) && ensure_bounds(h)) {
+            // decision pass: the register-resident kernel leaves the clip bounds of every round it can decide
+            a.bounds = h->d_bounds;
+            a.nrounds = h->d_nrounds;
+            const char *ignored = "";
+            NL_HIP(nl::launch_stack_sigma_decide(a, h->stream, mode == NL_ST_WINSOR_SIGMA, &ignored));
+        }
         const int64_t g = (a.npix + 3) / 4 < 65536 ? (a.npix + 3) / 4 : 65536;
         NL_HIP(nl::launch_stack_sigma_coop4(mode, a, (int)g, h->stream, &h->last_kernel));
         NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
@@ -847,6 +879,13 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         // no register-resident shortcut) and beyond 512 frames; with nl_stack_set_exact(h, 2) a
         // verification path
         h->last_used_fast = false;
+        if (weighted && h->exact_flavour == 0 && mode != NL_ST_MEDIAN && nl::decide_supported(mode, a.n_frames, a.npix) &&
+            ensure_bounds(h)) {
+            a.bounds = h->d_bounds;                    // decision pass, see the four-pixels-per-wave branch above
+            a.nrounds = h->d_nrounds;
+            const char *ignored = "";
+            NL_HIP(nl::launch_stack_sigma_decide(a, h->stream, mode == NL_ST_WINSOR_SIGMA, &ignored));
+        }
         const int64_t g = a.npix < 65536 ? a.npix : 65536;
         if (mode == NL_ST_MEDIAN) NL_HIP(nl::launch_stack_median_coop(a, (int)g, h->stream, &h->last_kernel));
         else                      NL_HIP(nl::launch_stack_sigma_coop(mode, a, (int)g, h->stream, &h->last_kernel));

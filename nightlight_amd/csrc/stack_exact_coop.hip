@@ -269,14 +269,26 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
         lds_fence();
 
         float res = p.ref_loc;
+        // weighted stacks with a decision pass (StackArgs::bounds): the clip bounds of this pixel's first `decided`
+        // rounds are on record -- those rounds only permute (the quickselect of QSelectMedian) and clip
+        int rnd = 0;
+        const int decided = (W && p.nrounds) ? (int)p.nrounds[pix] : 0;
         if (n > 0) {
             for (;;) {
+                float lo, hi, mean = 0.0f;
+                if (W && rnd < decided) {
+                    (void)coop_select(a, lpos, rfwd, n, (n >> 1) + 1);      // qsort.go:70 (the even-n scan of :73-81 does not permute)
+                    lds_fence();
+                    const float2 bd = p.bounds[(size_t)rnd * (size_t)p.npix + (size_t)pix];
+                    lo = bd.x;
+                    hi = bd.y;
+                } else {
                 const float median = coop_select_median(a, lpos, rfwd, n);
                 lds_fence();
                 // stats.go:246-261
                 const float fn = (float)n;
                 const float s = seq_sum(n, [&](int i) { return i < n ? a[i] : 0.0f; });
-                const float mean = s / fn;
+                mean = s / fn;
                 const float vs = seq_sum(n, [&](int i) {
                     const float d = (i < n ? a[i] : mean) - mean;
                     return i < n ? d * d : 0.0f;
@@ -316,7 +328,10 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
                     }
                 }
                 const float t_lo = p.sig_lo * sd, t_hi = p.sig_hi * sd;
-                const float lo = median - t_lo, hi = median + t_hi;
+                lo = median - t_lo;
+                hi = median + t_hi;
+                }
+                rnd++;
 
                 // stack.go:411-424: swap-with-last, re-test the same index
                 const int before = n;

@@ -233,12 +233,18 @@ __global__ __launch_bounds__(64) void stack_sigma_coop4_kernel(StackArgs p)
 
         float res = p.ref_loc;
         bool act = on && n > 0;
+        // weighted stacks with a decision pass (StackArgs::bounds): the clip bounds of a pixel's first `decided` rounds
+        // are on record; in those rounds its row only permutes and clips (zero-length sums, no winsorization)
+        int rnd = 0;
+        int decided = 0;
+        if (W && p.nrounds && on) decided = (int)p.nrounds[pix];
         while (__any(act)) {
+            const bool have = W && act && rnd < decided;
             const float median = coop_select_median4(a, lpos, rfwd, n, act, row, l16);
             fence4();
             // stats.go:246-261
             const float fn = (float)n;
-            const int na = act ? n : 0;
+            const int na = (act && !have) ? n : 0;
             const float s = seq_sum4(na, l16, [&](int i) { return i < na ? a[i] : 0.0f; });
             const float mean = s / fn;
             const float vs = seq_sum4(na, l16, [&](int i) {
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(64) void stack_sigma_coop4_kernel(StackArgs p)
                 const int top = rows_max(na);
                 for (int t = 0; t < top; t += 16)
                     if (t + l16 < na) wz[t + l16] = a[t + l16];
-                bool inner = act;
+                bool inner = act && !have;
                 while (__any(inner)) {
                     const float tt = 1.5f * sd;
                     const float wlo = median - tt, whi = median + tt;
@@ -285,7 +291,13 @@ __global__ __launch_bounds__(64) void stack_sigma_coop4_kernel(StackArgs p)
                 }
             }
             const float t_lo = p.sig_lo * sd, t_hi = p.sig_hi * sd;
-            const float lo = median - t_lo, hi = median + t_hi;
+            float lo = median - t_lo, hi = median + t_hi;
+            if (have) {
+                const float2 bd = p.bounds[(size_t)rnd * (size_t)p.npix + (size_t)pix];
+                lo = bd.x;
+                hi = bd.y;
+            }
+            rnd++;
 
             // stack.go:411-424: swap-with-last, re-test the same index.  Every trip of the loop a row either
             // scans one stretch of 16 for its next reject or removes the one it found.

@@ -359,13 +359,6 @@ void stack_mad_bitonic_kernel(StackArgs p, FastArgs q)
     }
 }
 
-// ZONAL = true : grid covers the tile, lane = pixel blockIdx*256+thread;
-// ZONAL = false: grid-stride over q.in_list (pixels handed over by the zonal
-//                kernel), any number of missing / clipped samples.
-// TIGHT (zonal only): the stack has exactly NS frames, so the only missing samples are a
-//                pixel's own NaNs -- the high zone reserves no positions for them (a third
-//                fewer zone positions to mask, count and re-sum every clipping round); a lane
-//                whose NaNs leave no survivor in the high zone goes to the generic pass as before.
 #ifdef NL_ROUND_STATS
 // developer statistics (build with make EXTRA=-DNL_ROUND_STATS): [0] winsor rounds executed by waves,
 // [1] rounds lanes needed, [2] clip passes executed by waves, [3] clip passes lanes needed, [4] waves
@@ -384,426 +377,9 @@ extern "C" int nl_debug_round_stats(unsigned long long *out, int reset)
 #define NL_STAT(i, x) ((void)0)
 #endif
 
-template <int NS, bool ZONAL, bool WINSOR, bool TIGHT>
-__global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
-{
-    static_assert(!TIGHT || ZONAL, "TIGHT is a variant of the zonal kernels");
-    if constexpr (ZONAL) fused_prologue_dominant(p);
-    if constexpr (!ZONAL) { if (q.in_list) { fused_collect_slots(p); snapshot_fb_list(q); } }
-    // zone widths: 8 clipped + 8 missing samples per lane for the larger
-    // networks, 4 + 4 for the small ones
-    constexpr int KZ = NS >= 48 ? kZone : 4, KP = TIGHT ? 0 : (NS >= 48 ? kPadMax : 4);
-    static_assert(!ZONAL || NS >= 24, "zonal passes need room between the zones");
-    constexpr int ZL = KZ;                                    // low zone  = positions [0, ZL)
-    constexpr int ZH = ZONAL ? NS - KZ - KP : NS;             // high zone = positions [ZH, NS)
-
-    int c_lo_total = 0, c_hi_total = 0;
-    // ZONAL, or GENERIC without a list: the grid covers the tile, one pixel per
-    // lane, a single trip.  GENERIC with a list: grid-stride over the hand-over
-    // list, whose length is only known on the device.
-    const bool listed = !ZONAL && q.in_list != nullptr;
-    const int64_t limit = listed ? (int64_t)min(*q.in_count, q.in_capacity) : p.npix;
-    const int64_t sweep = listed ? (int64_t)gridDim.x * blockDim.x : limit;
-    const int lane = threadIdx.x & 63;
-
-    for (int64_t wg_item = (int64_t)blockIdx.x * blockDim.x; wg_item < limit; wg_item += sweep) {
-        // the frame count is re-read through an opaque register every trip:
-        // otherwise the compiler hoists the 128 per-frame scalar selects that
-        // depend on it out of the loop and spills them
-        int N = p.n_frames;
-        asm volatile("" : "+s"(N));
-        const int64_t item = wg_item + threadIdx.x;
-        const bool on = item < limit;
-        int64_t pix = item;
-        if (listed) pix = on ? (int64_t)q.in_list[item] : 0;
-        const unsigned boff = (unsigned)(on ? pix : 0) * 4u;     // byte offset inside a frame
-
-        // A genuine +-Inf sample stays among the n valid ones, makes the variance
-        // non-finite and thereby sends the pixel to the exact kernel (`bail`).
-        // zonal sigma: only the clip zones and the median window need exact ranks (the
-        // winsorized variant also reads single positions in between: full sort)
-        constexpr int MW0 = ZONAL ? ZH / 2 - 1 : 0, MW1 = ZONAL ? ZL + NS / 2 + 1 : NS;
-        using Sorter = std::conditional_t<ZONAL && !WINSOR, ZonalSort<ZL, MW0, MW1, ZH>, FullSort>;
-        float v[NS];
-        const int n = gather_sorted<NS, 16, Sorter, true>(p.frames, p.stride, N, boff, v);
-        bool to_exact = false;
-
-        float res = p.ref_loc;
-        int c_lo = 0, c_hi = 0;
-        int a = 0, b = n;                       // surviving samples = sorted positions [a, b)
-        bool active = on && n > 0;
-        bool to_generic = false;
-        if constexpr (ZONAL) {
-            // zonal passes need b > ZH (and a < ZL): lanes with more missing
-            // samples are handed to the generic pass, the others carry on
-            to_generic = active && !(n > ZH);
-            active = active && !to_generic;
-        }
-
-        // Shift c = first-pass median (any value near the bulk works).  With
-        // D = sum(x-c) and Q = sum((x-c)^2) over the survivors,
-        //     mean = c + D/cnt,   var = Q/cnt - (mean-c)^2        (exact identities).
-        // Positions [ZL,ZH) are never clipped in the zonal passes, so their
-        // share of D and Q is computed once; an iteration only re-sums the zones.
-        constexpr int W0 = ZONAL ? ZH / 2 - 1 : 0, W1 = ZONAL ? ZL + NS / 2 + 1 : NS;
-        const float c = pick<W0, W1>(v, a + ((b - a) >> 1));
-        float d_mid = 0.0f, q_mid = 0.0f;
-        if constexpr (ZONAL) {
-            float d0 = 0, d1 = 0, d2 = 0, d3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-            static_chunks<0, (ZH - ZL) / 4, 4>([&](auto K) NL_INL {
-                constexpr int k = ZL + 4 * decltype(K)::value;
-                const float e0 = v[k] - c, e1 = v[k + 1] - c, e2 = v[k + 2] - c, e3 = v[k + 3] - c;
-                d0 += e0; d1 += e1; d2 += e2; d3 += e3;
-                q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
-                q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
-            });
-            d_mid = (d0 + d1) + (d2 + d3);
-            q_mid = (q0 + q1) + (q2 + q3);
-        }
-
-        // winsorization (stack.go:646-672) clamps at median -/+ 1.5 sigma: in the zonal
-        // passes only sorted positions outside [WL, WH) are allowed to reach a clamp,
-        // the inner half contributes these fixed sums
-        // (the clamps sit at +-1.5 sigma: 6.7 % of a Gaussian column per side, 8.6 +- 2.8 samples of 128;
-        // a pixel with more goes to the replay through shape_ok)
-#ifndef NL_WINSOR_WL
-#define NL_WINSOR_WL(ns) ((ns) >= 112 ? 20 : ((ns) >= 80 ? 16 : ((ns) / 4 + 3) / 4 * 4))
-#endif
-        constexpr int WL = ZONAL ? NL_WINSOR_WL(NS) : 0, WH = ZONAL ? NS - WL - KP : NS;
-        float d_in = 0.0f, q_in = 0.0f;
-        if constexpr (ZONAL && WINSOR) {
-            static_assert(WL >= ZL && WH <= ZH && (WL - ZL) % 4 == 0 && (WH - WL) % 4 == 0, "winsor zones");
-            float d0 = 0, d1 = 0, d2 = 0, d3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-            static_chunks<0, (WH - WL) / 4, 4>([&](auto K) NL_INL {
-                constexpr int k = WL + 4 * decltype(K)::value;
-                const float e0 = v[k] - c, e1 = v[k + 1] - c, e2 = v[k + 2] - c, e3 = v[k + 3] - c;
-                d0 += e0; d1 += e1; d2 += e2; d3 += e3;
-                q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
-                q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
-            });
-            d_in = (d0 + d1) + (d2 + d3);
-            q_in = (q0 + q1) + (q2 + q3);
-        }
-
-        // max|x| over the survivors (only enters the reference-mean error term):
-        // first pass from the two ends of the sorted column, afterwards from the
-        // bounds every survivor passed
-        float amax = fmaxf(fabsf(v[0]), fabsf(pick<ZONAL ? ZH : 0, NS>(v, n - 1)));
-
-        if (ZONAL && lane == 0) NL_STAT(4, 1);
-        while (__any(active)) {
-            if (ZONAL) { if (lane == 0) NL_STAT(2, 1); if (active) NL_STAT(3, 1); }
-            // re-materialised per pass: otherwise the differences v[k] - c of every masked
-            // position are hoisted out of the loop (one register each -- 128 in the generic pass;
-            // the 24 of the zonal sigma pass are left alone)
-            float cz = c;
-            if constexpr (!ZONAL || WINSOR) asm volatile("" : "+v"(cz));
-            const int cnt = b - a;
-            const float fcnt = (float)cnt;
-            float dz0 = 0.0f, dz1 = 0.0f, qz0 = 0.0f, qz1 = 0.0f;
-            if constexpr (ZONAL) {
-                static_range<0, ZL>([&](auto K) NL_INL {
-                    constexpr int k = decltype(K)::value;
-                    const float e = (k >= a) ? v[k] - cz : 0.0f;
-                    dz0 += e;
-                    qz0 = __builtin_fmaf(e, e, qz0);
-                });
-                static_range<ZH, NS>([&](auto K) NL_INL {
-                    constexpr int k = decltype(K)::value;
-                    const float e = (k < b) ? v[k] - cz : 0.0f;
-                    dz1 += e;
-                    qz1 = __builtin_fmaf(e, e, qz1);
-                });
-            } else {
-                const int a1 = opaque(a);
-                float dz2 = 0.0f, dz3 = 0.0f, qz2 = 0.0f, qz3 = 0.0f;
-                static_chunks<0, NS / 4, 2>([&](auto K) NL_INL {
-                    constexpr int k = 4 * decltype(K)::value;
-                    const bool i0 = (unsigned)(k + 0 - a1) < (unsigned)cnt;
-                    const bool i1 = (unsigned)(k + 1 - a1) < (unsigned)cnt;
-                    const bool i2 = (unsigned)(k + 2 - a1) < (unsigned)cnt;
-                    const bool i3 = (unsigned)(k + 3 - a1) < (unsigned)cnt;
-                    const float e0 = i0 ? v[k + 0] - cz : 0.0f, e1 = i1 ? v[k + 1] - cz : 0.0f;
-                    const float e2 = i2 ? v[k + 2] - cz : 0.0f, e3 = i3 ? v[k + 3] - cz : 0.0f;
-                    dz0 += e0; dz1 += e1; dz2 += e2; dz3 += e3;
-                    qz0 = __builtin_fmaf(e0, e0, qz0); qz1 = __builtin_fmaf(e1, e1, qz1);
-                    qz2 = __builtin_fmaf(e2, e2, qz2); qz3 = __builtin_fmaf(e3, e3, qz3);
-                });
-                dz0 += dz2; dz1 += dz3; qz0 += qz2; qz1 += qz3;
-            }
-            const float dsum = d_mid + (dz0 + dz1);
-            const float qsum = q_mid + (qz0 + qz1);
-            const float delta = dsum / fcnt;             // mean~ - c
-            const float m = c + delta;
-            const float aa = qsum / fcnt;                // E[(x-c)^2]~
-            const float bb = delta * delta;
-            const float var = fmaxf(aa - bb, 0.0f);
-
-            // ---- bracket the reference's stddev ----
-            // ours: aa carries <= NS/4+8 roundings per term; bb = delta^2 with delta off by
-            // <= (NS/4+7) u mean|e|, and 2|delta| mean|e| <= aa + bb: together <= (NS/2+17) u (aa+bb)
-            const float err_o = ((float)(NS / 2 + 24)) * kU * (aa + bb);
-            // reference: relative gamma_(n+3) on its variance, its mean off by <= e_m
-            const float eps_r = 1.02f * (fcnt + 8.0f) * kU;
-            const float e_m = 1.02f * (fcnt + 2.0f) * kU * amax;
-            const float v_up = var + err_o;
-            const float v_dn = fmaxf(var - err_o, 0.0f);
-            const float v_hi = v_up + v_up * eps_r + e_m * e_m;
-            const float v_lo = fmaxf(v_dn - v_dn * eps_r, 0.0f);
-            float s_max = __fsqrt_rn(v_hi) * (1.0f + 4.0f * kU);
-            float s_min = __fsqrt_rn(v_lo) * (1.0f - 4.0f * kU);
-            bool bail = !(v_hi < 3.0e38f);          // overflow / NaN (e.g. an Inf sample): exact kernel
-
-            // ---- exact median (qsort.go:68-82): sorted column, position lookup ----
-            // zonal: a in [0,ZL), b in (ZH,NS]  =>  kk in [ZH/2, ZL-1+NS/2]
-            const int kk = a + (cnt >> 1);
-            float upper, lower;
-            pick_pair<W0, W1>(v, kk, lower, upper);
-            const float median = (cnt & 1) ? upper : 0.5f * (lower + upper);
-
-            if constexpr (WINSOR) {
-                // ---- winsorized stddev, stack.go:646-672, as an interval ----
-                // The reference repeats { clamp a copy to median -/+ 1.5*std; std =
-                // 1.134*stddev(copy) } until nothing changed or std moved by <= 0.05 %.
-                // Its std is again an order-dependent fp32 sum, so we carry an interval
-                // [w_lo, w_hi] for it through the loop (WinsorInterval, fast_common.hpp).
-                constexpr int PZ = ZONAL ? ZH : 0;
-                const float xmin = pick<0, ZONAL ? ZL : NS>(v, a);
-                const float xmax = pick<PZ, NS>(v, b - 1);
-                WinsorInterval wi;
-                wi.start(s_min, s_max);
-                const float inv_cnt = 1.0f / fcnt;
-                bool inner = active && !bail;
-                while (__any(inner)) {
-                    if (ZONAL) { if (lane == 0) NL_STAT(0, 1); if (inner) NL_STAT(1, 1); }
-                    wi.next_clamp(median, xmin, xmax);
-                    // variance of clamp(x, Lt, Ht) over the survivors (shifted moments) and its error bound
-                    auto clamped_variance = [&](const float Lt, const float Ht, float &wvar, float &werr, float &wmean_c,
-                                                float &wrms) NL_INL {
-                    float d0 = 0, d1 = 0, d2 = 0, d3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-                    if constexpr (ZONAL) {
-                        // only the outer quarters of the sorted column can sit on a clamp
-                        // (checked below); the inner half enters unclamped through d_in / q_in
-                        static_range<0, ZL>([&](auto K) NL_INL {
-                            constexpr int k = decltype(K)::value;
-                            const float e = (k >= a) ? max_raw(v[k], Lt) - cz : 0.0f;
-                            d0 += e; q0 = __builtin_fmaf(e, e, q0);
-                        });
-                        static_chunks<0, (WL - ZL) / 4, 2>([&](auto K) NL_INL {
-                            constexpr int k = ZL + 4 * decltype(K)::value;
-                            const float e0 = max_raw(v[k], Lt) - cz, e1 = max_raw(v[k + 1], Lt) - cz;
-                            const float e2 = max_raw(v[k + 2], Lt) - cz, e3 = max_raw(v[k + 3], Lt) - cz;
-                            d0 += e0; d1 += e1; d2 += e2; d3 += e3;
-                            q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
-                            q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
-                        });
-                        static_chunks<0, (ZH - WH) / 4, 2>([&](auto K) NL_INL {
-                            constexpr int k = WH + 4 * decltype(K)::value;
-                            const float e0 = min_raw(v[k], Ht) - cz, e1 = min_raw(v[k + 1], Ht) - cz;
-                            const float e2 = min_raw(v[k + 2], Ht) - cz, e3 = min_raw(v[k + 3], Ht) - cz;
-                            d0 += e0; d1 += e1; d2 += e2; d3 += e3;
-                            q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
-                            q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
-                        });
-                        static_range<ZH, NS>([&](auto K) NL_INL {
-                            constexpr int k = decltype(K)::value;
-                            const float e = (k < b) ? min_raw(v[k], Ht) - cz : 0.0f;
-                            d1 += e; q1 = __builtin_fmaf(e, e, q1);
-                        });
-                        d2 += d_in; q2 += q_in;
-                    } else {
-                        const int a4 = opaque(a);
-                        static_chunks<0, NS / 4, 2>([&](auto K) NL_INL {
-                            constexpr int k = 4 * decltype(K)::value;
-                            const bool i0 = (unsigned)(k + 0 - a4) < (unsigned)cnt;
-                            const bool i1 = (unsigned)(k + 1 - a4) < (unsigned)cnt;
-                            const bool i2 = (unsigned)(k + 2 - a4) < (unsigned)cnt;
-                            const bool i3 = (unsigned)(k + 3 - a4) < (unsigned)cnt;
-                            const float e0 = i0 ? __builtin_amdgcn_fmed3f(v[k + 0], Lt, Ht) - cz : 0.0f;
-                            const float e1 = i1 ? __builtin_amdgcn_fmed3f(v[k + 1], Lt, Ht) - cz : 0.0f;
-                            const float e2 = i2 ? __builtin_amdgcn_fmed3f(v[k + 2], Lt, Ht) - cz : 0.0f;
-                            const float e3 = i3 ? __builtin_amdgcn_fmed3f(v[k + 3], Lt, Ht) - cz : 0.0f;
-                            d0 += e0; d1 += e1; d2 += e2; d3 += e3;
-                            q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
-                            q2 = __builtin_fmaf(e2, e2, q2); q3 = __builtin_fmaf(e3, e3, q3);
-                        });
-                    }
-                    const float wd = ((d0 + d1) + (d2 + d3)) * inv_cnt;      // reciprocal: 2 more roundings,
-                    const float wa = ((q0 + q1) + (q2 + q3)) * inv_cnt;      // covered by werr
-                    const float wb = wd * wd;
-                    wvar = fmaxf(wa - wb, 0.0f);
-                    werr = ((float)(NS / 2 + 34)) * kU * (wa + wb);
-                    wmean_c = wd;                                  // mean of the copy, minus c
-                    wrms = wa;                                     // E[(copy - c)^2]
-                    };
-                    float var_t, err_t, wd_t, wa_t;
-                    clamped_variance(wi.Lp, wi.Hm, var_t, err_t, wd_t, wa_t);
-                    // The loosest clamp (Lm, Hp) is not evaluated: with y = the copy at the tightest
-                    // clamp and z = the copy at the loosest, z - y = delta is non-zero only for the
-                    // n_lo samples below Lp (delta in [-(Lp-Lm), 0], y = Lp there) and the n_hi samples
-                    // above Hm (delta in [0, Hp-Hm], y = Hm), so
-                    //   var(z) = var(y) + 2 cov(y, delta) + var(delta)
-                    //         <= var(y) + [n_lo dL (2 (ybar-Lp) + dL) + n_hi dH (2 (Hm-ybar) + dH)] / cnt.
-                    // n_lo, n_hi only need upper bounds: the column is sorted, so testing every 4th
-                    // position (every 2nd, every one for the small networks) bounds them to +3.
-                    // (CS = 1 for the small networks: +3 on a handful of clamped samples would loosen the bound)
-                    constexpr int CS = NS >= 64 ? 4 : (NS >= 48 ? 2 : 1);
-                    int t_lo = 0, t_hi = 0;
-                    if constexpr (ZONAL) {
-                        static_range<0, WL / CS>([&](auto J) NL_INL {
-                            constexpr int k = CS * decltype(J)::value + CS - 1;
-                            const bool below = v[k] < wi.Lp;
-                            t_lo += ((k >= ZL || k >= a) && below) ? 1 : 0;
-                        });
-                        static_range<0, (NS - WH) / CS>([&](auto J) NL_INL {
-                            constexpr int k = WH + CS * decltype(J)::value;
-                            const bool above = v[k] > wi.Hm;
-                            t_hi += ((k < ZH || k < b) && above) ? 1 : 0;
-                        });
-                    } else {
-                        const int a5 = opaque(a);
-                        static_range<0, NS / CS>([&](auto J) NL_INL {
-                            constexpr int k = CS * decltype(J)::value;
-                            const bool in_lo = (unsigned)(k + CS - 1 - a5) < (unsigned)cnt;
-                            const bool in_hi = (unsigned)(k - a5) < (unsigned)cnt;
-                            t_lo += (in_lo && v[k + CS - 1] < wi.Lp) ? 1 : 0;
-                            t_hi += (in_hi && v[k] > wi.Hm) ? 1 : 0;
-                        });
-                    }
-                    float var_l, err_l;
-                    {
-                        const float n_lo = (float)min(CS * t_lo + CS - 1, cnt), n_hi = (float)min(CS * t_hi + CS - 1, cnt);
-                        const float dL = (wi.Lp - wi.Lm) * (1.0f + 2.0f * kU), dH = (wi.Hp - wi.Hm) * (1.0f + 2.0f * kU);
-                        // ybar = cz + wd_t, off by <= (NS/4+8) u mean|y-c| <= 3e-6 sqrt(E[(y-c)^2]) plus its own rounding
-                        const float ybar = cz + wd_t;
-                        const float slop = 4.0e-6f * __builtin_amdgcn_sqrtf(wa_t) + 4.0f * kU * fabsf(ybar) + 1.0e-30f;
-                        const float gL = fmaxf(ybar - wi.Lp, 0.0f) + slop, gH = fmaxf(wi.Hm - ybar, 0.0f) + slop;
-                        const float corr = (n_lo * (dL * (2.0f * gL + dL)) + n_hi * (dH * (2.0f * gH + dH))) * inv_cnt;
-                        // an infinite clamp width (first round: Lm = Lp = -Inf gives Inf - Inf) cannot occur:
-                        // both ends of an interval are finite or the same infinity -> NaN -> 0
-                        var_l = var_t + ((corr == corr) ? corr * 1.001f : 0.0f);
-                        err_l = err_t;
-                    }
-                    // zonal: the inner half must be strictly inside every clamp of the interval
-                    const bool shape_ok = !ZONAL || (v[WL] >= wi.Lp && v[WH - 1] <= wi.Hm);
-                    wi.finish_round(var_t, err_t, var_l, err_l, eps_r, e_m, shape_ok, inner, bail);
-                }
-                s_min = wi.hull_lo;
-                s_max = wi.hull_hi;
-            }
-
-            // ---- the reference's bound expressions at both ends of the interval ----
-            // (stack.go:408-409; fp32 multiply then add, never fused)
-            const float tl0 = __fmul_rn(p.sig_lo, s_min), tl1 = __fmul_rn(p.sig_lo, s_max);
-            const float th0 = __fmul_rn(p.sig_hi, s_min), th1 = __fmul_rn(p.sig_hi, s_max);
-            const float la = __fsub_rn(median, tl0), lb = __fsub_rn(median, tl1);
-            const float ha = __fadd_rn(median, th0), hb = __fadd_rn(median, th1);
-            const float lo_min = fminf(la, lb), lo_max = fmaxf(la, lb);
-            const float hi_min = fminf(ha, hb), hi_max = fmaxf(ha, hb);
-
-            // ---- count certain clips (c1,d1) and possible clips (c2,d2) ----
-            // The column is sorted, so the samples below a threshold are a prefix and
-            // those above it a suffix (pads are +Inf): count over the whole zone
-            // without rank masks and subtract what is already excluded.
-            int c1 = 0, c2 = 0, d1 = 0, d2 = 0;
-            if constexpr (ZONAL) {
-                static_range<0, ZL>([&](auto K) NL_INL {
-                    constexpr int k = decltype(K)::value;
-                    c1 += (v[k] < lo_min) ? 1 : 0;
-                    c2 += (v[k] < lo_max) ? 1 : 0;
-                });
-                static_range<ZH, NS>([&](auto K) NL_INL {
-                    constexpr int k = decltype(K)::value;
-                    d1 += (v[k] > hi_max) ? 1 : 0;
-                    d2 += (v[k] > hi_min) ? 1 : 0;
-                });
-                c1 = max(c1 - a, 0); c2 = max(c2 - a, 0);
-                d1 = max(d1 - (NS - b), 0); d2 = max(d2 - (NS - b), 0);
-                // the zones must still hold a survivor on each side, otherwise the
-                // next sorted position (outside the zone) might be clipped as well:
-                // such a lane restarts in the generic pass
-                if (active && ((a + c2 >= ZL) || (b - d2 <= ZH))) {
-                    to_generic = true;
-                    active = false;
-                }
-            } else {
-                static_chunks<0, NS, 8>([&](auto K) NL_INL {
-                    constexpr int k = decltype(K)::value;
-                    const float x = v[k];
-                    c1 += (x < lo_min) ? 1 : 0;
-                    c2 += (x < lo_max) ? 1 : 0;
-                    d1 += (x > hi_max) ? 1 : 0;
-                    d2 += (x > hi_min) ? 1 : 0;
-                });
-                c1 = min(max(c1 - a, 0), cnt); c2 = min(max(c2 - a, 0), cnt);
-                d1 = min(max(d1 - (NS - b), 0), cnt); d2 = min(max(d2 - (NS - b), 0), cnt);
-            }
-            if (active) {
-                // a sample inside the window, or (negative sigma) inverted bounds where the
-                // reference's "low first" order matters: let the exact kernel decide
-                bail |= (c1 != c2) || (d1 != d2) || (lo_max > hi_min && (c1 + d1) > 0);
-                if (bail) {
-                    to_exact = true;
-                    active = false;
-                } else {
-                    c_lo += c1;
-                    c_hi += d1;
-                    a += c1;
-                    b -= d1;
-                    amax = fminf(amax, fmaxf(fabsf(lo_min), fabsf(hi_max)));   // survivors lie in [lo_min, hi_max]
-                    if ((c1 + d1) == 0 || (b - a) <= 1) {     // stack.go:427-430: mean BEFORE this pass
-                        res = m;
-                        active = false;
-                    }
-                }
-            }
-        }
-
-        if (on && !to_generic && !to_exact) {
-            p.out[pix] = res;
-            c_lo_total += c_lo;
-            c_hi_total += c_hi;
-        }
-        // hand-over lists: one atomic per wave reserves a contiguous run, lanes
-        // fill it in lane order, so the consumer's loads stay coalesced
-        if constexpr (ZONAL) {
-            const unsigned long long gm = __ballot(on && to_generic);
-            if (gm) {
-                unsigned base = 0;
-                if (lane == 0) base = atomicAdd(q.gen_count, (unsigned)__popcll(gm));
-                base = __shfl(base, 0, 64);
-                const unsigned slot = base + (unsigned)__popcll(gm & ((1ull << lane) - 1ull));
-                if (on && to_generic && slot < q.gen_capacity) q.gen_list[slot] = (unsigned)pix;
-            }
-        }
-        const unsigned long long em = __ballot(on && to_exact);
-        if (em) {
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(q.fb_count, (unsigned)__popcll(em));
-            base = __shfl(base, 0, 64);
-            const unsigned slot = base + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
-            if (on && to_exact && slot < q.fb_capacity) q.fb_list[slot] = (unsigned)pix;
-        }
-    }
-
-    // clip totals: wave sum -> block sum -> one slot per workgroup
-    __shared__ int s_lo[4], s_hi[4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        c_lo_total += __shfl_xor(c_lo_total, o, 64);
-        c_hi_total += __shfl_xor(c_hi_total, o, 64);
-    }
-    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = c_lo_total; s_hi[threadIdx.x >> 6] = c_hi_total; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t_lo = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3];
-        const int t_hi = s_hi[0] + s_hi[1] + s_hi[2] + s_hi[3];
-        unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
-        if constexpr (!ZONAL) slot = clip_slot(p);
-        if (t_lo) atomicAdd(slot + 0, (unsigned long long)t_lo);
-        if (t_hi) atomicAdd(slot + 1, (unsigned long long)t_hi);
-    }
-}
+}  // namespace nl
+#include "stack_fast_sigma_impl.hpp"
+namespace nl {
 
 int fast_supported(int mode, bool weighted, int n_frames, int64_t npix)
 {

@@ -45,6 +45,11 @@ struct StackArgs {
     // reduce_counters_kernel).
     unsigned long long *final;    // [2] clip totals of the pass
     unsigned long long *zero_next;
+    // Weighted stacks, decision pass + permutation replay (stack_fast_decide.hip): thresholds that reproduce the
+    // reference's clip decisions, [round][pixel] (round stride = npix), and the number of rounds per pixel (0 = not
+    // decided: the replay computes its own bounds, as without these).  nullptr: off.
+    float2 *bounds;
+    unsigned char *nrounds;
 };
 
 // words (64 bit) of one per-pass scratch set: clip accumulators + {exact-list length, generic-list length,
@@ -185,6 +190,13 @@ hipError_t launch_stack_sigma_mlz(const StackArgs &args, const FastArgs &fargs, 
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
                                    const char **name, hipEvent_t dominant_done,
                                    bool winsor, AfterDominant after_dominant, void *user);
+
+// rounds of clip bounds a decision pass records per pixel (pixels that need more are replayed in full)
+constexpr int kBoundRounds = 8;
+// ---- stack_fast_decide.hip: the register-resident kernels as the DECISION pass of weighted sigma / winsorized
+// stacks (StackArgs::bounds / nrounds); 45..128 frames ----
+int decide_supported(int mode, int n_frames, int64_t npix);
+hipError_t launch_stack_sigma_decide(const StackArgs &args, hipStream_t stream, bool winsor, const char **name);
 
 // ---- stack_fast_ml.hip (129..512 frames, 2 or 4 lanes per pixel) ----
 int fast_ml_supported(int mode, bool weighted, int n_frames, int64_t npix);

@@ -745,6 +745,13 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         // register-resident fast kernel; pixels it cannot decide go to the exact kernel
         nl::FastArgs f;
         memset(&f, 0, sizeof f);
+        // winsorized passes: the fast kernels put the thresholds of every round they decide on record, so that the
+        // replay of a pixel that turns undecidable later skips the winsorization loops of the decided rounds
+        // (not with the developer switches that bring back round-1 kernels, which write no round counts)
+        if (mode == NL_ST_WINSOR_SIGMA && fused_on && ensure_bounds(h)) {
+            a.bounds = h->d_bounds;
+            a.nrounds = h->d_nrounds;
+        }
         f.fb_list = h->d_fb_list;
         f.fb_count = h->d_fb_count;
         f.fb_capacity = (unsigned)h->npix;

@@ -269,14 +269,15 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
         lds_fence();
 
         float res = p.ref_loc;
-        // weighted stacks with a decision pass (StackArgs::bounds): the clip bounds of this pixel's first `decided`
-        // rounds are on record -- those rounds only permute (the quickselect of QSelectMedian) and clip
+        // StackArgs::bounds (weighted stacks with a decision pass; list replays of winsorized passes): the clip
+        // bounds of this pixel's first `decided` rounds are on record -- those rounds only permute (the quickselect of
+        // QSelectMedian) and clip.  An unweighted result is the mean of the LAST round, which is never on record.
         int rnd = 0;
-        const int decided = (W && p.nrounds) ? (int)p.nrounds[pix] : 0;
+        const int decided = p.nrounds ? (int)p.nrounds[pix] : 0;
         if (n > 0) {
             for (;;) {
                 float lo, hi, mean = 0.0f;
-                if (W && rnd < decided) {
+                if (rnd < decided) {
                     (void)coop_select(a, lpos, rfwd, n, (n >> 1) + 1);      // qsort.go:70 (the even-n scan of :73-81 does not permute)
                     lds_fence();
                     const float2 bd = p.bounds[(size_t)rnd * (size_t)p.npix + (size_t)pix];

@@ -373,6 +373,7 @@ void stack_sigma_mlg_kernel(StackArgs p, FastArgs q)
             c_lo_total += c_lo;
             c_hi_total += c_hi;
         }
+        if (rep && to_exact && p.nrounds) p.nrounds[pix] = 0;       // (no decided rounds on record for the replay)
         const unsigned long long em = __ballot(rep && to_exact);
         if (em) {
             unsigned base = 0;

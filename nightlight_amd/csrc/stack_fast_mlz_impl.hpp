@@ -442,6 +442,7 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
 
     float res = p.ref_loc;
     int c_lo = 0, c_hi = 0;
+    int rnd = 0;                                           // winsorized: clipping rounds decided so far (StackArgs::bounds)
     int a = 0, b = n;                                      // survivors = sorted ranks [a, b)
     constexpr float kErrF = (float)(2 * L::ROUNDINGS + 8);
 
@@ -634,7 +635,17 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
             if (bail) {
                 to_exact = true;
                 active = false;
+                if constexpr (WINSOR) { if (p.nrounds && role == 0) p.nrounds[pix] = (unsigned char)min(rnd, kBoundRounds); }
             } else {
+                if constexpr (WINSOR) {
+                    // the thresholds of a decided round go on record: should the pixel turn undecidable later, its
+                    // replay skips the winsorization loop of this round (stack_fast_sigma_impl.hpp)
+                    if (p.bounds) {
+                        if (rnd < kBoundRounds && role == 0)
+                            p.bounds[(size_t)rnd * (size_t)p.npix + (size_t)pix] = make_float2(lo_max, hi_min);
+                        rnd++;
+                    }
+                }
                 c_lo += c1;
                 c_hi += d1;
                 a += c1;

@@ -386,7 +386,19 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                 if (bail) {
                     to_exact = true;
                     active = false;
+                    // winsorized passes: the rounds decided so far are on record for the replay (see below)
+                    // (the generic instantiation records nothing: 0 rounds)
+                    if constexpr (WINSOR && !RECORD) { if (p.nrounds) p.nrounds[pix] = (unsigned char)(ZONAL ? min(rnd, kBoundRounds) : 0); }
                 } else {
+                    if constexpr (WINSOR && ZONAL && !RECORD) {
+                        // A pixel that turns undecidable in a LATER round is replayed from scratch -- but the
+                        // rounds decided before that need no winsorization loop in the replay (about 20 sequential
+                        // sums each): their thresholds go on record as in the decision pass of weighted stacks
+                        if (p.bounds) {
+                            if (rnd < kBoundRounds) p.bounds[(size_t)rnd * (size_t)p.npix + (size_t)pix] = make_float2(lo_max, hi_min);
+                            rnd++;
+                        }
+                    }
                     if constexpr (RECORD) {
                         // x < lo_max <=> x < the reference's bound, x > hi_min <=> x > its bound, for every surviving
                         // sample: none lies in [lo_min, lo_max) or (hi_min, hi_max] (c1 == c2, d1 == d2)

@@ -1,9 +1,5 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-bash tools/qb.sh "--weighted --no-cpu" "--weighted --mode 3 --no-cpu" "--weighted --frames 96 --no-cpu" "--weighted --frames 64 --no-cpu" "--weighted --frames 64 --mode 3 --no-cpu"
-NL_WDECIDE=0 bash tools/qb.sh "--weighted --no-cpu" "--weighted --mode 3 --no-cpu"
-python bench.py --weighted --steps 5 --warmup 2 --no-also 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['ms_per_step'], d['cpu_baseline']['parity_with_gpu'])"
-python bench.py --weighted --mode 3 --steps 3 --warmup 1 --no-also 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['ms_per_step'], d['cpu_baseline']['parity_with_gpu'])"
+python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+NL_FUZZ_N=30,130 NL_FUZZ_MODES=2,3 python tests/sweeps/fuzz_parity.py 30000 41 2>&1 | tail -2
+python tests/sweeps/fuzz_parity.py 20000 42 2>&1 | tail -2
+timeout 300 tools/gpu_profile.sh wsigma128 --weighted > /dev/null 2>&1
+timeout 400 tools/gpu_profile.sh wwinsor128 --weighted --mode 3 > /dev/null 2>&1

@@ -748,7 +748,9 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         // winsorized passes: the fast kernels put the thresholds of every round they decide on record, so that the
         // replay of a pixel that turns undecidable later skips the winsorization loops of the decided rounds
         // (not with the developer switches that bring back round-1 kernels, which write no round counts)
-        if (mode == NL_ST_WINSOR_SIGMA && fused_on && ensure_bounds(h)) {
+        // (from 129 frames on: C3 tile 5.28 -> 5.14 ms; at 128 frames most undecidable pixels are undecidable in
+        // their first round and the stores cost the dominant kernel 0.6 %)
+        if (mode == NL_ST_WINSOR_SIGMA && a.n_frames > 128 && fused_on && ensure_bounds(h)) {
             a.bounds = h->d_bounds;
             a.nrounds = h->d_nrounds;
         }

@@ -482,13 +482,13 @@ hipError_t launch_stack_mad_fast(const StackArgs &args, const FastArgs &fargs, h
 // smallest network size with a zonal instantiation
 constexpr int kZonalMinSize = 24;
 
-// kernel names as rocprofv3 prints them (template arguments: NS, ZONAL, WINSOR, TIGHT)
+// kernel names as rocprofv3 prints them (template arguments: NS, ZONAL, WINSOR, TIGHT, RECORD)
 template <int NS, bool ZONAL, bool WINSOR, bool TIGHT>
 static const char *sigma_kernel_name()
 {
     static const std::string name = std::string("stack_sigma_fast_kernel<") + std::to_string(NS) + ", " +
                                     (ZONAL ? "true" : "false") + ", " + (WINSOR ? "true" : "false") + ", " +
-                                    (TIGHT ? "true" : "false") + ">";
+                                    (TIGHT ? "true" : "false") + ", false>";
     return name.c_str();
 }
 

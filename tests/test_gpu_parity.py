@@ -98,7 +98,7 @@ def test_tight_zonal_variant_exact_sizes(nl, oracle, mode, n, nan_frac):
         st.set_exact(False)
         got, cl, ch = st.run(mode, 2.5, 2.0, 0.0)
         name = st.last_kernel_name
-    assert name == "stack_sigma_fast_kernel<%d, true, %s, true>" % (n, "true" if mode == 3 else "false"), name
+    assert name == "stack_sigma_fast_kernel<%d, true, %s, true, false>" % (n, "true" if mode == 3 else "false"), name
     rc, want, wl, wh, _ = oracle.stack_apply(mode, frames, None, 2.5, 2.0, 0.0, num_cpu=4)
     assert rc == 0
     assert (cl, ch) == (wl, wh), "n=%d mode=%d clip counters %r vs oracle %r" % (n, mode, (cl, ch), (wl, wh))

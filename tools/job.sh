@@ -1,5 +1,7 @@
 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-python tools/ab_flags.py 3 512 512 1536 4096 3 0,4
-python tools/ab_flags.py 3 128 4096 0 4096 3 0,4
-python tools/ab_flags.py 3 300 1024 0 4096 2 0,4
-NL_FUZZ_N=20,512 NL_FUZZ_MODES=3 python tests/sweeps/fuzz_parity.py 6000 51 2>&1 | tail -2
+P=tools/gpu_profile.sh
+timeout 300 $P sigma128 > /dev/null 2>&1
+timeout 300 $P sigma128tile --height 512 --row0 1536 --image-height 4096 > /dev/null 2>&1
+timeout 300 $P sigma32 --frames 32 > /dev/null 2>&1
+timeout 300 $P winsor128 --mode 3 > /dev/null 2>&1
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err

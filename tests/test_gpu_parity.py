@@ -707,3 +707,25 @@ def test_goal_seek_on_modes_without_sigmas_stacks_once(nl, oracle):
             out, cl, ch, sl, sh, passes = st.find_sigmas(mode, 1.0, 1.0)
             rc, want, _, _, _ = oracle.stack_apply(mode, frames, None, 0.0, 0.0)
             assert (passes, sl, sh) == (1, 0.0, 0.0) and same_values(out, want)
+
+
+@pytest.mark.parametrize("mode,n,weighted", [(2, 128, False), (3, 128, False), (3, 300, False), (2, 512, False),
+                                             (2, 100, True), (3, 64, True), (3, 128, True)])
+def test_developer_switches_do_not_change_results(nl, oracle, mode, n, weighted):
+    # nl_stack_set_dev_flags: plain pass protocol (1), replay in front of the generic pass (2), no decision pass /
+    # no recorded rounds (4) -- and a second pass on the same handle (fused protocol, grids sized from the first
+    # pass's list lengths): every combination must give the bits and the counters of the default
+    width, height = 4096, 12
+    with nl.StackHandle(n, width, 4096, row0=0, rows=height) as st:
+        st.fill_synthetic(5)
+        if weighted:
+            st.set_weights(np.random.default_rng(n).uniform(0.2, 1.0, n).astype(np.float32))
+        ref = None
+        for flags in (0, 0, 1, 2, 4, 7, 0):
+            st.set_dev_flags(flags)
+            got, cl, ch = st.run(mode, 3.0, 2.5)
+            got = got[:height * width]
+            if ref is None:
+                ref = (got.copy(), cl, ch)
+            assert (cl, ch) == ref[1:], (flags, cl, ch, ref[1:])
+            assert np.array_equal(got.view(np.uint32), ref[0].view(np.uint32)), flags

@@ -349,7 +349,7 @@ def verify_bitonic(ns, keep_ends, ops, out, n_slots, trials=400, seed=3):
     assert np.array_equal(np.sort(y, axis=1), ref), (ns, keep_ends, "set")
 
 
-BITONIC = ((128, 0), (128, 16), (128, 32))       # (size, KEEP): the merges of the multi-lane kernels
+BITONIC = ((128, 0), (128, 16), (128, 32), (64, 0), (32, 0), (16, 0))       # (size, KEEP): the merges of the multi-lane kernels; the cascades of the selection front end
 
 
 def variants():

@@ -1,7 +1,3 @@
 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-P=tools/gpu_profile.sh
-timeout 300 $P sigma128 > /dev/null 2>&1
-timeout 300 $P sigma128tile --height 512 --row0 1536 --image-height 4096 > /dev/null 2>&1
-timeout 300 $P sigma32 --frames 32 > /dev/null 2>&1
-timeout 300 $P winsor128 --mode 3 > /dev/null 2>&1
-timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+python tools/ab_flags.py 2 512 4096 0 4096 3 0 | cut -c1-170
+NL_FUZZ_N=497,512 NL_FUZZ_MODES=2 python tests/sweeps/fuzz_parity.py 3000 61 2>&1 | tail -1

@@ -193,12 +193,20 @@ __device__ __forceinline__ void ml_sort_merge(float (&v)[NS], int role)
 // ENDS_ONLY: the last merge orders only the KEEP lowest / highest ranks of every lane.
 // The gather alone: the lane's samples as loaded, NaN and missing frames as +Inf; returns the number of valid
 // samples of the PIXEL (all its lanes).
-template <int LPP, int NS>
+// KPAD0 / NLOAD (frame-count classes, stack_fast_mlz_impl.hpp): positions below KPAD0 always hold a frame, positions from
+// NLOAD on never do -- they are +Inf without a load -- and only the few in between depend on the frame count: those become
+// +Inf directly and stay out of the finiteness test, so that a wave without NaN samples skips the NaN count although its
+// lanes are not full (with the defaults every lane of a stack that does not fill its lanes takes the 640-instruction
+// count in every wave).
+template <int LPP, int NS, int KPAD0 = NS / 2, int NLOAD = NS>
 __device__ __forceinline__ int ml_gather_raw(const float *frames, int64_t stride, int N, bool on, int64_t pix,
                                              int role, float (&v)[NS])
 {
-int nan_cnt = 0;
-{
+    static_assert(KPAD0 <= NLOAD && NLOAD <= NS, "positions");
+    constexpr bool CLASS = !(KPAD0 == NS / 2 && NLOAD == NS);
+    int nan_cnt = 0;
+    int spad = NS - NLOAD;                                   // positions of this lane without a frame
+    {
         // Frames are dealt round-robin: lane role r takes frames r, r+LPP, ...
         // (any split works, the column is sorted afterwards).  Buffer loads: one
         // scalar descriptor per register index k covering frames k*LPP .. k*LPP+LPP-1,
@@ -212,7 +220,7 @@ int nan_cnt = 0;
         // item loop as loop invariants and spilled
         asm volatile("" : "+s"(frame_bytes));
         const int voff = (int)((unsigned)(on ? pix : 0) * 4u) + role * frame_bytes;
-        static_chunks<0, NS, 4>([&](auto K) NL_INL {
+        static_chunks<0, NLOAD, 4>([&](auto K) NL_INL {
             constexpr int k = decltype(K)::value;
             const int avail = min(max(N - k * LPP, 0), LPP);                // frames this descriptor covers
             const char *gb = reinterpret_cast<const char *>(frames) + (int64_t)(k * LPP) * frame_bytes;
@@ -220,39 +228,57 @@ int nan_cnt = 0;
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gb), 0, avail * frame_bytes, 0x00020000);
             v[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
         });
-        // frame k*LPP+role >= N: missing (NaN).  Only k >= KPAD0 can be affected:
-        // this kernel is used for N > NT/2.
-        constexpr int KPAD0 = NS / 2;
+        static_range<NLOAD, NS>([&](auto K) NL_INL { v[decltype(K)::value] = __builtin_inff(); });
         int lastp = opaque(N - 1) - role;
-        static_chunks<KPAD0, NS, 8>([&](auto K) NL_INL {
-            constexpr int k = decltype(K)::value;
-            if constexpr ((k & 7) == 0) lastp = opaque(lastp);
-            const int pad = (lastp - k * LPP) >> 31;                           // all ones -> NaN
-            v[k] = __int_as_float(__float_as_int(v[k]) | pad);
-        });
-        // clean waves skip the NaN count (see gather_sorted in fast_common.hpp)
         float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
-        static_chunks<0, NS / 4, 8>([&](auto K) NL_INL {
-            constexpr int k = 4 * decltype(K)::value;
-            t0 += v[k]; t1 += v[k + 1]; t2 += v[k + 2]; t3 += v[k + 3];
-        });
+        if constexpr (CLASS) {
+            // frame k*LPP+role >= N: no frame -> +Inf, counted, kept out of the sum below
+            float tp = 0.0f;
+            static_range<KPAD0, NLOAD>([&](auto K) NL_INL {
+                constexpr int k = decltype(K)::value;
+                const int pad = (lastp - k * LPP) >> 31;                       // all ones: no frame
+                tp += __int_as_float(__float_as_int(v[k]) & ~pad);
+                v[k] = __int_as_float((__float_as_int(v[k]) & ~pad) | (0x7f800000 & pad));
+                spad -= pad;
+            });
+            static_chunks<0, KPAD0 / 4, 8>([&](auto K) NL_INL {
+                constexpr int k = 4 * decltype(K)::value;
+                t0 += v[k]; t1 += v[k + 1]; t2 += v[k + 2]; t3 += v[k + 3];
+            });
+            static_range<KPAD0 / 4 * 4, KPAD0>([&](auto K) NL_INL { t0 += v[decltype(K)::value]; });
+            t0 += tp;
+        } else {
+            // frame k*LPP+role >= N: missing (NaN).  Only k >= KPAD0 can be affected:
+            // this kernel is used for N > NT/2.
+            static_chunks<KPAD0, NS, 8>([&](auto K) NL_INL {
+                constexpr int k = decltype(K)::value;
+                if constexpr ((k & 7) == 0) lastp = opaque(lastp);
+                const int pad = (lastp - k * LPP) >> 31;                           // all ones -> NaN
+                v[k] = __int_as_float(__float_as_int(v[k]) | pad);
+            });
+            // clean waves skip the NaN count (see gather_sorted in fast_common.hpp)
+            static_chunks<0, NS / 4, 8>([&](auto K) NL_INL {
+                constexpr int k = 4 * decltype(K)::value;
+                t0 += v[k]; t1 += v[k + 1]; t2 += v[k + 2]; t3 += v[k + 3];
+            });
+        }
         const float total = (t0 + t1) + (t2 + t3);
         if (__any(!(__builtin_fabsf(total) < __builtin_inff()))) {
-            static_chunks<0, NS, 8>([&](auto K) NL_INL {
+            static_chunks<0, NLOAD, 8>([&](auto K) NL_INL {
                 constexpr int k = decltype(K)::value;
                 nan_cnt = opaque(nan_cnt - ((0x7f800000 - (__float_as_int(v[k]) & 0x7fffffff)) >> 31));
                 asm volatile("v_min_f32 %0, %0, %1" : "+v"(v[k]) : "v"(__builtin_inff()));   // NaN -> +Inf in place
             });
         }
     }
-    return quad_sum<LPP>(NS - nan_cnt);
+    return quad_sum<LPP>(NS - nan_cnt - spad);
 }
 
-template <int LPP, int NS, bool ENDS_ONLY, int KEEP = 16, int CH = 32, int NSL = NS>
+template <int LPP, int NS, bool ENDS_ONLY, int KEEP = 16, int CH = 32, int NSL = NS, int KPAD0 = NS / 2, int NLOAD = NS>
 __device__ __forceinline__ int ml_gather_sorted(const float *frames, int64_t stride, int N, bool on, int64_t pix,
                                                 int role, float (&v)[NS])
 {
-    const int n = ml_gather_raw<LPP, NS>(frames, stride, N, on, pix, role, v);
+    const int n = ml_gather_raw<LPP, NS, KPAD0, NLOAD>(frames, stride, N, on, pix, role, v);
     ml_sort_merge<LPP, NS, ENDS_ONLY, KEEP, CH, NSL>(v, role);
     return n;
 }

@@ -299,10 +299,11 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     // columns of a shorter stack sit inside the lanes: full merge
     int n;
     if constexpr (L::SELECT) {
-        n = ml_gather_raw<LPP, NS>(p.frames, p.stride, N, on, pix, role, v);
+        n = ml_gather_raw<LPP, NS, (NTOP - 16) / LPP, NTOP / LPP>(p.frames, p.stride, N, on, pix, role, v);
         sort_network<NS>(v);                               // the lanes' runs are not merged: select_ends / select_window
     } else {
-        n = ml_gather_sorted<LPP, NS, L::FULL && !WINSOR, 32, 32, L::NSL>(p.frames, p.stride, N, on, pix, role, v);
+        n = ml_gather_sorted<LPP, NS, L::FULL && !WINSOR, 32, 32, L::NSL, (NTOP - 16) / LPP, NTOP / LPP>(p.frames, p.stride, N, on, pix,
+                                                                                                              role, v);
     }
 
     // ---- columns and median window to LDS ----

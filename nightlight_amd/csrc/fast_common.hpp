@@ -327,7 +327,8 @@ __device__ __forceinline__ float nan_to_inf(float x)
 // last frame, so unused positions re-read a valid address.
 // GAP: the caller guarantees N > NS - GAP (distance to its next smaller network size).
 // SORT: FullSort, or ZonalSort<...> where only part of the order is needed.
-template <int NS, int GAP = 16, class SORT = FullSort, bool NT = false>
+// PADDED = false: the caller knows N == NS (no unused positions).
+template <int NS, int GAP = 16, class SORT = FullSort, bool NT = false, bool PADDED = true>
 __device__ __forceinline__ int gather_sorted(const float *frames, int64_t stride, int N,
                                              unsigned boff, float (&v)[NS])
 {
@@ -354,20 +355,24 @@ __device__ __forceinline__ int gather_sorted(const float *frames, int64_t stride
             v[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)boff, soff, NT ? 2 : 0));
         });
     });
-    // unused positions k >= N (N > NS - GAP by the choice of NS) become NaN = missing
-    static_range<(NS > GAP ? NS - GAP : 0), NS>([&](auto K) NL_INL {
+    // Unused positions k >= N (N > NS - GAP by the choice of NS) hold no frame: +Inf (they sort last), and they stay
+    // out of the finiteness test below -- otherwise every wave of a stack whose frame count is not a network size
+    // would take the NaN count (about 4 instructions per position) for the sake of its own padding.
+    // Clean waves (no lane holds a NaN or an infinite sample -- everything but the aligned frames' borders) skip the
+    // NaN count: a plain fp32 sum of the column is finite iff every sample is.  (A sum that overflows only costs the count.)
+    constexpr int P0 = !PADDED ? NS : (NS > GAP ? NS - GAP : 0);
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+    static_range<P0, NS>([&](auto K) NL_INL {
         constexpr int k = decltype(K)::value;
         const int pad = (N - 1 - k) >> 31;                        // scalar: N is uniform
-        v[k] = __int_as_float(__float_as_int(v[k]) | pad);
+        t0 += __int_as_float(__float_as_int(v[k]) & ~pad);
+        v[k] = __int_as_float((__float_as_int(v[k]) & ~pad) | (0x7f800000 & pad));
     });
-    // Clean waves (no lane holds a NaN or an infinite sample -- everything but the
-    // aligned frames' borders) skip the NaN count: a plain fp32 sum of the column is
-    // finite iff every sample is.  (A sum that overflows only costs the count.)
-    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
-    static_chunks<0, NS / 4, 8>([&](auto K) NL_INL {
+    static_chunks<0, P0 / 4, 8>([&](auto K) NL_INL {
         constexpr int k = 4 * decltype(K)::value;
         t0 += v[k]; t1 += v[k + 1]; t2 += v[k + 2]; t3 += v[k + 3];
     });
+    static_range<P0 / 4 * 4, P0>([&](auto K) NL_INL { t1 += v[decltype(K)::value]; });
     const float total = (t0 + t1) + (t2 + t3);
     int nan_cnt = 0;
     if (__any(!(__builtin_fabsf(total) < __builtin_inff()))) {
@@ -381,7 +386,7 @@ __device__ __forceinline__ int gather_sorted(const float *frames, int64_t stride
         });
     }
     SORT::template apply<NS>(v);
-    return NS - nan_cnt;
+    return min(N, NS) - nan_cnt;                              // (the padding is +Inf, not NaN: not in nan_cnt)
 }
 
 // ---- winsorization loop of StackWinsorSigma (stack.go:646-672) on intervals ------

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         constexpr int MW0 = ZONAL ? ZH / 2 - 1 : 0, MW1 = ZONAL ? ZL + NS / 2 + 1 : NS;
         using Sorter = std::conditional_t<ZONAL && !WINSOR, ZonalSort<ZL, MW0, MW1, ZH>, FullSort>;
         float v[NS];
-        const int n = gather_sorted<NS, 16, Sorter, true>(p.frames, p.stride, N, boff, v);
+        const int n = gather_sorted<NS, 16, Sorter, true, !TIGHT>(p.frames, p.stride, N, boff, v);
         bool to_exact = false;
 
         float res = p.ref_loc;

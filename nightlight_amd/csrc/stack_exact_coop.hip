@@ -18,14 +18,45 @@
 // The pixel's column lives in LDS as a plain array (n_frames floats per wave;
 // the winsorized variant keeps its clamped copy in a second one).
 #include "stack_kernels.h"
+#include <stdlib.h>
 
 namespace nl {
+
+#ifdef NL_PROBE
+__device__ unsigned long long nl_probe_cycles[8];
+#define NL_T0() nl_t = (long long)__builtin_readcyclecounter()
+#define NL_T(slot) do { const long long nl_n = (long long)__builtin_readcyclecounter(); nl_acc[slot] += nl_n - nl_t; nl_t = nl_n; } while (0)
+#define NL_TDECL() long long nl_t = 0, nl_acc[5] = {0, 0, 0, 0, 0}
+#define NL_TFLUSH() do { if (threadIdx.x == 0) for (int q = 0; q < 5; q++) atomicAdd(&nl_probe_cycles[q], (unsigned long long)nl_acc[q]); } while (0)
+#else
+#define NL_T0() do {} while (0)
+#define NL_T(slot) do {} while (0)
+#define NL_TDECL() do {} while (0)
+#define NL_TFLUSH() do {} while (0)
+#endif
 
 namespace {
 
 __device__ __forceinline__ float sqrt_like_go(float x)      // stats.go:259
 {
     return (float)__builtin_sqrt((double)x);
+}
+
+__device__ __forceinline__ unsigned long long ballot64(bool p)      // the compare's own wave mask (HIP's __ballot goes
+{                                                                    // through an integer: v_cndmask + v_cmp_ne on top)
+    return __builtin_amdgcn_ballot_w64(p);
+}
+
+__device__ __forceinline__ int below64(unsigned long long m)         // set bits of m below this lane: two v_mbcnt
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+__device__ __forceinline__ int first_lane(unsigned long long m)      // lowest set bit, -1 for an empty mask (s_ff1's own answer;
+{                                                                    // __builtin_ffsll wraps it in a compare and a select)
+    int r;
+    asm("s_ff1_i32_b64 %0, %1" : "=s"(r) : "s"(m));
+    return r;
 }
 
 __device__ __forceinline__ void lds_fence()
@@ -64,6 +95,46 @@ __device__ __forceinline__ float seq_sum(int n, F &&elem)
     return s;
 }
 
+// Two independent sequential sums at once (the weighted mean's numerator and denominator, stack.go:514-522):
+// one occupies lanes 0..31, the other lanes 32..63, 32 elements of each per step, and they swap halves from step
+// to step so that the carry is a single wave rotation (lane 31 -> 32, lane 63 -> 0).  Inside a half the chain is
+// two 16-lane rows: 15 row shifts, lane 15 broadcast into the next row, 15 row shifts -- 32 VALU instructions per
+// 32 + 32 elements instead of 2 x 63 per 64 + 64.  Lanes that are not yet final hold anything: a final value only
+// ever comes from a final neighbour (see chain64).  `s`: the previous step's register (0.0f before the first).
+__device__ __forceinline__ float chain32x2(float s, float x)
+{
+#define NL_ROW(mask) "v_add_f32_dpp %0, %0, %1 row_shr:1 row_mask:" mask " bank_mask:0xf\n\ts_nop 1\n\t"
+#define NL_ROW15(mask) NL_ROW(mask) NL_ROW(mask) NL_ROW(mask) NL_ROW(mask) NL_ROW(mask) NL_ROW(mask) NL_ROW(mask) NL_ROW(mask) \
+                       NL_ROW(mask) NL_ROW(mask) NL_ROW(mask) NL_ROW(mask) NL_ROW(mask) NL_ROW(mask) NL_ROW(mask)
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %1 wave_ror:1 row_mask:0x5 bank_mask:0x1\n\ts_nop 1\n\t"
+                 NL_ROW15("0x5")
+                 "v_add_f32_dpp %0, %0, %1 row_bcast:15 row_mask:0xa bank_mask:0x1\n\ts_nop 1\n\t"
+                 NL_ROW15("0xa")
+                 : "+v"(s) : "v"(x));
+#undef NL_ROW15
+#undef NL_ROW
+    return s;
+}
+
+// sums of ea(i) and eb(i), i = 0 .. n-1, each in index order; the loaders deliver +0.0f past n
+template <class FA, class FB>
+__device__ __forceinline__ void seq_sum2(int n, FA &&ea, FB &&eb, float &sum_a, float &sum_b)
+{
+    const int lane = threadIdx.x;
+    float s = 0.0f;
+    int c = 0;
+    for (int base = 0; base < n; base += 32, c++) {
+        const int i = base + (lane & 31);
+        const bool first = (((lane >> 5) ^ c) & 1) == 0;     // the half that holds the first sum in this step
+        s = chain32x2(s, first ? ea(i) : eb(i));
+    }
+    const float e31 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 31));
+    const float e63 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
+    sum_a = (c & 1) ? e31 : e63;                             // the last step was c - 1
+    sum_b = (c & 1) ? e63 : e31;
+}
+
 // The partition passes of a select whose range [left, right] has shrunk to at most 63 elements, in REGISTERS:
 // lane i holds a[left + i]; a pass is two ballots, the candidate tables through ds_permute (lane t receives the
 // position of the t-th candidate from the left / from the right; lanes that have nothing to send aim at lane 63,
@@ -73,43 +144,49 @@ __device__ __forceinline__ float seq_sum(int n, F &&elem)
 __device__ float coop_select_small(float *a, int left, int right, int k)
 {
     const int lane = threadIdx.x;
-    int lo = 0, hi = right - left;
+    int lo = 0, hi = __builtin_amdgcn_readfirstlane(right - left);
+    const int target = __builtin_amdgcn_readfirstlane(k) - 1;         // position of the wanted element: lo + k - 1 never changes
     const bool mine = lane <= hi;
     float x = mine ? a[left + lane] : 0.0f;
-    const unsigned long long below = (1ull << lane) - 1ull;
     constexpr int kTrash = 63 * 4;
+    // With eight waves per SIMD the replay is bound by the ISSUE of scalar and vector instructions alike (about 40 of
+    // each per pass at first; cycle probes, tools/coop_probe.py), so a pass is written for few of both: the
+    // classification lives in wave masks (a v_cmp IS the ballot; HIP's __ballot goes through an integer), ranks come
+    // from v_mbcnt, the range mask from one s_bfm, nothing in the loop body branches, and who swaps follows from
+    // the ranks alone, without tables of candidate positions:
+    //   the L-candidate at position p with rank t (t candidates below it) swaps  <=>  L_t < R_t
+    //        <=>  at least t + 1 R-candidates lie above p;
+    //   the R-candidate at position q with rank u (u candidates above it) swaps  <=>  at least u + 1 L-candidates lie below q.
+    // Each side then scatters its values to the lane of their rank (ds_permute) and the swapping candidates of the
+    // other side fetch the value of their own rank (ds_bpermute): two dependent LDS-crossbar trips instead of three.
+    // The pass ends at r = max(R_s, L_{s-1}): the position of the candidate whose rank is s (s - 1), by s_ff1 over
+    // the classification mask (-1 when there is none, as the formula wants).
     while (lo < hi) {
         const int pm = (lo + hi) >> 1;                       // (left + right) >> 1, relative to left
         const float pivot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), pm));
-        const bool in = lane >= lo && lane <= hi;
-        const bool isl = in && x >= pivot;
-        const bool isr = in && x <= pivot;
-        const unsigned long long ml = __ballot(isl), mr = __ballot(isr);
-        const int nl = __popcll(ml), nr = __popcll(mr);
-        const int rl = __popcll(ml & below);                 // rank among the candidates from the left
-        const int rr = __popcll((mr >> 1) >> lane);          // rank among the candidates from the right
-        const int lt = __builtin_amdgcn_ds_permute(isl ? rl * 4 : kTrash, lane);     // lane t: L_t
-        const int rt = __builtin_amdgcn_ds_permute(isr ? rr * 4 : kTrash, lane);     // lane t: R_t
-        const int pairs = min(nl, nr);
-        const bool ok = lane < pairs && lt < rt;             // monotone in the lane
-        const int s_cnt = __popcll(__ballot(ok));
-        const bool sw = lane < s_cnt;
-        const int xl = __builtin_amdgcn_ds_bpermute(lt * 4, __float_as_int(x));
-        const int xr = __builtin_amdgcn_ds_bpermute(rt * 4, __float_as_int(x));
-        const int to_l = __builtin_amdgcn_ds_permute(sw ? lt * 4 : kTrash, xr);      // position L_t receives a[R_t]
-        const int to_r = __builtin_amdgcn_ds_permute(sw ? rt * 4 : kTrash, xl);
-        if (isl && rl < s_cnt) x = __int_as_float(to_l);     // (no position is both: see coop_select)
-        else if (isr && rr < s_cnt) x = __int_as_float(to_r);
-        const int r_next = s_cnt < nr ? __builtin_amdgcn_readlane(rt, s_cnt) : -1;
-        const int l_prev = s_cnt > 0 ? __builtin_amdgcn_readlane(lt, s_cnt - 1) : -1;
-        const int r = max(r_next, l_prev);
-        const int offset = r - lo + 1;
-        if (k <= offset) {
-            hi = r;
-        } else {
-            lo = r + 1;
-            k -= offset;
-        }
+        unsigned long long in;                               // lanes lo .. hi (hi <= 62)
+        asm("s_bfm_b64 %0, %1, %2" : "=s"(in) : "s"(hi - lo + 1), "s"(lo));
+        const unsigned long long ml = ballot64(x >= pivot) & in;
+        const unsigned long long mr = ballot64(x <= pivot) & in;
+        const bool isl = __builtin_amdgcn_inverse_ballot_w64(ml), isr = __builtin_amdgcn_inverse_ballot_w64(mr);
+        const int nr = __popcll(mr);
+        const int rl = below64(ml);                          // L-candidates below this position
+        const int ra = nr - below64(mr) - (isr ? 1 : 0);     // R-candidates above this position
+        const unsigned long long sl = ml & ballot64(ra > rl);                         // the swapping L-candidates (rank rl) ...
+        const unsigned long long sr = mr & ballot64(rl > ra);                         // ... and R-candidates (rank ra); never both
+        const int s_cnt = __popcll(sl);
+        const int val_r = __builtin_amdgcn_ds_permute(isr ? ra * 4 : kTrash, __float_as_int(x));      // lane t: a[R_t]
+        const int val_l = __builtin_amdgcn_ds_permute(isl ? rl * 4 : kTrash, __float_as_int(x));      // lane t: a[L_t]
+        const int from_r = __builtin_amdgcn_ds_bpermute(rl * 4, val_r);
+        const int from_l = __builtin_amdgcn_ds_bpermute(ra * 4, val_l);
+        const int r_s = first_lane(mr & ballot64(ra == s_cnt));                       // R_s, -1 if there is none
+        const int l_p = first_lane(ml & ballot64(rl == s_cnt - 1));                   // L_{s-1}
+        int xi = __float_as_int(x);
+        xi = __builtin_amdgcn_inverse_ballot_w64(sl) ? from_r : xi;
+        xi = __builtin_amdgcn_inverse_ballot_w64(sr) ? from_l : xi;
+        x = __int_as_float(xi);
+        const int r = max(r_s, l_p);
+        if (target <= r) hi = r; else lo = r + 1;            // k <= r - lo + 1, with k = target - lo + 1
     }
     if (mine) a[left + lane] = x;
     const float res = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lo));
@@ -134,10 +211,22 @@ __device__ float coop_select_small(float *a, int left, int right, int k)
 __device__ float coop_select(float *a, unsigned short *lpos, unsigned short *rfwd, int n, int k)
 {
     const int lane = threadIdx.x;
-    const unsigned long long below = (1ull << lane) - 1ull;
     int left = 0, right = n - 1;
+#ifdef NL_PROBE
+    long long pt0 = (long long)__builtin_readcyclecounter();
+#endif
     while (left < right) {
-        if (right - left < 63) return coop_select_small(a, left, right, k);
+        if (right - left < 63) {
+#ifdef NL_PROBE
+            const long long pt1 = (long long)__builtin_readcyclecounter();
+            const float rs = coop_select_small(a, left, right, k);
+            const long long pt2 = (long long)__builtin_readcyclecounter();
+            if (threadIdx.x == 0) { atomicAdd(&nl_probe_cycles[5], (unsigned long long)(pt1 - pt0)); atomicAdd(&nl_probe_cycles[6], (unsigned long long)(pt2 - pt1)); }
+            return rs;
+#else
+            return coop_select_small(a, left, right, k);
+#endif
+        }
         const float pivot = a[(left + right) >> 1];
         // classify, and list the misplaced positions in scan order
         int nl = 0, nr = 0;
@@ -147,9 +236,9 @@ __device__ float coop_select(float *a, unsigned short *lpos, unsigned short *rfw
             const float x = in ? a[idx] : 0.0f;
             const bool isl = in && x >= pivot;
             const bool isr = in && x <= pivot;
-            const unsigned long long ml = __ballot(isl), mr = __ballot(isr);
-            if (isl) lpos[nl + __popcll(ml & below)] = (unsigned short)idx;         // (positions < 65536 by coop_supported: 16 bits, half the LDS)
-            if (isr) rfwd[nr + __popcll(mr & below)] = (unsigned short)idx;         // ascending; R_i = rfwd[nr-1-i]
+            const unsigned long long ml = ballot64(isl), mr = ballot64(isr);
+            if (isl) lpos[nl + below64(ml)] = (unsigned short)idx;         // (positions < 65536 by coop_supported: 16 bits, half the LDS)
+            if (isr) rfwd[nr + below64(mr)] = (unsigned short)idx;         // ascending; R_i = rfwd[nr-1-i]
             nl += __popcll(ml);
             nr += __popcll(mr);
         }
@@ -160,7 +249,7 @@ __device__ float coop_select(float *a, unsigned short *lpos, unsigned short *rfw
         for (int base = 0; base < pairs; base += 64) {
             const int i = base + lane;
             const bool ok = i < pairs && (int)lpos[i] < (int)rfwd[nr - 1 - i];
-            const unsigned long long m = __ballot(ok);
+            const unsigned long long m = ballot64(ok);
             s_cnt += __popcll(m);
             if (m != ~0ull) break;
         }
@@ -212,7 +301,14 @@ __device__ float coop_select_median(float *a, unsigned short *lpos, unsigned sho
 // W: weighted variants (stack.go:442-531, 710-829).  The weights live in their own column and
 // follow only the clip swaps -- quickselect permutes the samples, NOT the weights
 // (stack.go:487), and the weighted mean pairs them index by index all the same.
-template <bool WINSOR, bool W>
+//
+// BLK: pixels per work item of a replay over the WHOLE tile (no list).  With BLK = 1 a wave gathers its pixel
+// straight from HBM, 4 bytes out of every line it touches: the weighted 128-frame stack fetched 13 x its
+// algorithmic bytes and, once the decision pass had removed the chains, ran at the speed of those fetches
+// (2.9 TB/s of mostly unused lines).  With BLK = 16 a wave first stages the columns of 16 consecutive pixels
+// in LDS -- every frame contributes one 64-byte segment, four of them per load instruction -- and replays
+// them one after the other from there: the frames are read once.
+template <bool WINSOR, bool W, int BLK>
 __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
 {
     extern __shared__ float a[];
@@ -220,6 +316,8 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
     float *wt = a + (WINSOR ? 2 : 1) * p.n_frames;          // weights (W only)
     unsigned short *lpos = reinterpret_cast<unsigned short *>(a + ((WINSOR ? 2 : 1) + (W ? 1 : 0)) * p.n_frames);   // partition scratch, 2 x n_frames x 16 bit
     unsigned short *rfwd = lpos + p.n_frames;
+    float *blk = a + ((WINSOR ? 2 : 1) + (W ? 1 : 0) + 1) * p.n_frames;      // BLK > 1: [pixel][frame], odd row length
+    const int NP = p.n_frames | 1;
     const int lane = threadIdx.x;
     const int N = p.n_frames;
     int64_t limit = p.npix;
@@ -229,6 +327,7 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
         limit = cnt < p.list_capacity ? cnt : p.list_capacity;
     }
     long long c_lo = 0, c_hi = 0;
+    NL_TDECL();
 
     int64_t first = 0;
     if (p.list && p.list_snap) {
@@ -250,24 +349,56 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
     // measured).  XCD x takes the x-th eighth of every sweep instead: neighbours run side by side under one L2.
     int64_t wg = blockIdx.x;
     if (!p.list && (gridDim.x & 7u) == 0u) wg = (int64_t)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if constexpr (BLK > 1) limit = (p.npix + BLK - 1) / BLK;          // (never with a list)
     for (int64_t item = first + wg; item < limit; item += gridDim.x) {
-        const int64_t pix = p.list ? (int64_t)p.list[item] : item;
+      int in_item = 1;
+      int64_t pix0 = item;
+      if constexpr (BLK > 1) {
+        static_assert(BLK == 16, "the staging loop maps 16 lanes to the pixels of a block");
+        pix0 = item * BLK;
+        in_item = (int)min((int64_t)BLK, p.npix - pix0);
+        lds_fence();
+        const int j = lane & 15;
+        const float *src = p.frames + pix0 + (j < in_item ? j : 0);
+        float *dst = blk + j * NP;
+        for (int k0 = lane >> 4; k0 < N; k0 += 32) {              // 4 frames per instruction, 8 instructions in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = k0 + 4 * u;
+                v[u] = k < N ? src[(int64_t)k * p.stride] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = k0 + 4 * u;
+                if (k < N) dst[k] = v[u];
+            }
+        }
+      } else if (p.list) {
+        pix0 = (int64_t)p.list[item];
+      }
+      for (int j = 0; j < in_item; j++) {
+        const int64_t pix = pix0 + j;
         const float *fr = p.frames + pix;
+        NL_T0();
         lds_fence();
         // ---- gather in frame order, NaN dropped (stack.go:380-387) ----
         int n = 0;
         for (int base = 0; base < N; base += 64) {
             const int k = base + lane;
-            const float x = k < N ? fr[(int64_t)k * p.stride] : __builtin_nanf("");
+            float x = __builtin_nanf("");
+            if constexpr (BLK > 1) { if (k < N) x = blk[j * NP + k]; }
+            else                   { if (k < N) x = fr[(int64_t)k * p.stride]; }
             const bool valid = x == x;
-            const unsigned long long m = __ballot(valid);
-            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+            const unsigned long long m = ballot64(valid);
+            const int pos = n + below64(m);
             if (valid) a[pos] = x;
             if (W && valid) wt[pos] = p.weights[k];                   // stack.go:452-459
             n += __popcll(m);
         }
         lds_fence();
 
+        NL_T(0);
         float res = p.ref_loc;
         // StackArgs::bounds (weighted stacks with a decision pass; list replays of winsorized passes): the clip
         // bounds of this pixel's first `decided` rounds are on record -- those rounds only permute (the quickselect of
@@ -280,6 +411,7 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
                 if (rnd < decided) {
                     (void)coop_select(a, lpos, rfwd, n, (n >> 1) + 1);      // qsort.go:70 (the even-n scan of :73-81 does not permute)
                     lds_fence();
+                    NL_T(1);
                     const float2 bd = p.bounds[(size_t)rnd * (size_t)p.npix + (size_t)pix];
                     lo = bd.x;
                     hi = bd.y;
@@ -312,7 +444,7 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
                             const bool above = idx < n && !below && x > whi;
                             if (below) wz[idx] = wlo;
                             if (above) wz[idx] = whi;
-                            changed += __popcll(__ballot(below || above));
+                            changed += __popcll(ballot64(below || above));
                         }
                         lds_fence();
                         const float ws = seq_sum(n, [&](int i) { return i < n ? wz[i] : 0.0f; });
@@ -333,6 +465,7 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
                 hi = median + t_hi;
                 }
                 rnd++;
+                NL_T(2);
 
                 // stack.go:411-424: swap-with-last, re-test the same index
                 const int before = n;
@@ -343,7 +476,7 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
                         const int idx = base + lane;
                         const float x = idx < n ? a[idx] : 0.0f;
                         const bool clipped = idx < n && (x < lo || x > hi);
-                        const unsigned long long m = __ballot(clipped);
+                        const unsigned long long m = ballot64(clipped);
                         if (m) { found = base + __builtin_ctzll(m); break; }
                     }
                     if (found < 0) break;
@@ -358,11 +491,13 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
                     n--;
                     j = found;
                 }
+                NL_T(3);
                 if (n == before || n <= 1) {
                     res = mean;                                   // stack.go:427-430: mean before this pass
                     if constexpr (W) {                            // stack.go:514-522: weighted mean of the survivors
-                        const float sw = seq_sum(n, [&](int i) { return i < n ? a[i] * wt[i] : 0.0f; });
-                        const float ws = seq_sum(n, [&](int i) { return i < n ? wt[i] : 0.0f; });
+                        float sw, ws;
+                        seq_sum2(n, [&](int i) { return i < n ? a[i] * wt[i] : 0.0f; },
+                                 [&](int i) { return i < n ? wt[i] : 0.0f; }, sw, ws);
                         res = sw / ws;
                     }
                     break;
@@ -370,7 +505,10 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
             }
         }
         if (lane == 0) p.out[pix] = res;
+        NL_T(4);
+      }
     }
+    NL_TFLUSH();
     if (lane == 0) {
         // fused pass protocol (StackArgs::final): straight to the totals; the replay of the generic pass's
         // additions is the last kernel of a pass and leaves the list lengths behind them ({exact | generic << 32}:
@@ -402,8 +540,8 @@ __global__ __launch_bounds__(64) void stack_median_coop_kernel(StackArgs p)
             const int k = base + lane;
             const float x = k < N ? fr[(int64_t)k * p.stride] : __builtin_nanf("");
             const bool valid = x == x;
-            const unsigned long long m = __ballot(valid);
-            if (valid) a[n + __popcll(m & ((1ull << lane) - 1ull))] = x;
+            const unsigned long long m = ballot64(valid);
+            if (valid) a[n + below64(m)] = x;
             n += __popcll(m);
         }
         lds_fence();
@@ -432,28 +570,48 @@ int coop_supported(int mode, bool weighted, int n_frames)
     return (n_frames <= 65535 && (size_t)n_frames * coop_columns(mode, weighted) * sizeof(float) <= 64 * 1024) ? 1 : 0;
 }
 
-hipError_t launch_stack_sigma_coop(int mode, const StackArgs &args, int grid, hipStream_t stream, const char **name)
+// dense replays of stacks up to kCoopBlockMaxFrames stage 16 pixels at a time (16 x n_frames x 4 bytes of LDS on top)
+constexpr int kCoopBlock = 16, kCoopBlockMaxFrames = 256;
+
+template <bool WINSOR, bool W>
+static hipError_t launch_coop(const StackArgs &args, int grid, size_t lds, hipStream_t stream, const char **name)
 {
-    const bool weighted = args.weights != nullptr;
-    const size_t lds = (size_t)args.n_frames * sizeof(float) * coop_columns(mode, weighted);
-    if (mode == NL_ST_WINSOR_SIGMA) {
-        if (weighted) {
-            *name = "stack_sigma_coop_kernel<true, true>";
-            hipLaunchKernelGGL((stack_sigma_coop_kernel<true, true>), dim3(grid), dim3(64), lds, stream, args);
-        } else {
-            *name = "stack_sigma_coop_kernel<true, false>";
-            hipLaunchKernelGGL((stack_sigma_coop_kernel<true, false>), dim3(grid), dim3(64), lds, stream, args);
-        }
+    static const int forced = getenv("NL_COOP_BLOCK") ? atoi(getenv("NL_COOP_BLOCK")) : -1;     // development switch
+    if (forced == kCoopBlock && !args.list && args.n_frames <= kCoopBlockMaxFrames && args.npix >= 64 * kCoopBlock) {
+        const int64_t blocks = (args.npix + kCoopBlock - 1) / kCoopBlock;
+        int g = (int)(blocks < (int64_t)grid ? blocks : (int64_t)grid);
+        if (g > 8) g &= ~7;                              // whole sweeps for the XCD-contiguous mapping
+        *name = WINSOR ? (W ? "stack_sigma_coop_kernel<true, true, 16>" : "stack_sigma_coop_kernel<true, false, 16>")
+                       : (W ? "stack_sigma_coop_kernel<false, true, 16>" : "stack_sigma_coop_kernel<false, false, 16>");
+        const size_t staged = lds + (size_t)kCoopBlock * (size_t)(args.n_frames | 1) * sizeof(float);
+        hipLaunchKernelGGL((stack_sigma_coop_kernel<WINSOR, W, kCoopBlock>), dim3(g), dim3(64), staged, stream, args);
     } else {
-        if (weighted) {
-            *name = "stack_sigma_coop_kernel<false, true>";
-            hipLaunchKernelGGL((stack_sigma_coop_kernel<false, true>), dim3(grid), dim3(64), lds, stream, args);
-        } else {
-            *name = "stack_sigma_coop_kernel<false, false>";
-            hipLaunchKernelGGL((stack_sigma_coop_kernel<false, false>), dim3(grid), dim3(64), lds, stream, args);
-        }
+        *name = WINSOR ? (W ? "stack_sigma_coop_kernel<true, true, 1>" : "stack_sigma_coop_kernel<true, false, 1>")
+                       : (W ? "stack_sigma_coop_kernel<false, true, 1>" : "stack_sigma_coop_kernel<false, false, 1>");
+        hipLaunchKernelGGL((stack_sigma_coop_kernel<WINSOR, W, 1>), dim3(grid), dim3(64), lds, stream, args);
     }
     return hipGetLastError();
 }
 
+hipError_t launch_stack_sigma_coop(int mode, const StackArgs &args, int grid, hipStream_t stream, const char **name)
+{
+    const bool weighted = args.weights != nullptr;
+    const size_t lds = (size_t)args.n_frames * sizeof(float) * coop_columns(mode, weighted);
+    if (mode == NL_ST_WINSOR_SIGMA)
+        return weighted ? launch_coop<true, true>(args, grid, lds, stream, name) : launch_coop<true, false>(args, grid, lds, stream, name);
+    return weighted ? launch_coop<false, true>(args, grid, lds, stream, name) : launch_coop<false, false>(args, grid, lds, stream, name);
+}
+
 }  // namespace nl
+
+#ifdef NL_PROBE
+extern "C" int nl_debug_probe(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nl::nl_probe_cycles), sizeof(nl::nl_probe_cycles)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(nl::nl_probe_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -26,8 +26,11 @@ namespace nl {
 __device__ unsigned long long nl_probe_cycles[8];
 #define NL_T0() nl_t = (long long)__builtin_readcyclecounter()
 #define NL_T(slot) do { const long long nl_n = (long long)__builtin_readcyclecounter(); nl_acc[slot] += nl_n - nl_t; nl_t = nl_n; } while (0)
-#define NL_TDECL() long long nl_t = 0, nl_acc[5] = {0, 0, 0, 0, 0}
-#define NL_TFLUSH() do { if (threadIdx.x == 0) for (int q = 0; q < 5; q++) atomicAdd(&nl_probe_cycles[q], (unsigned long long)nl_acc[q]); } while (0)
+#define NL_TDECL() long long nl_t = 0, nl_acc[5] = {0, 0, 0, 0, 0}; const long long nl_c0 = (long long)__builtin_readcyclecounter(), nl_r0 = (long long)__builtin_amdgcn_s_memrealtime()
+#define NL_TFLUSH() do { if (threadIdx.x == 0) { for (int q = 0; q < 5; q++) atomicAdd(&nl_probe_cycles[q], (unsigned long long)nl_acc[q]); \
+        atomicAdd(&nl_probe_cycles[5], (unsigned long long)((long long)__builtin_readcyclecounter() - nl_c0)); \
+        const unsigned long long nl_w = (unsigned long long)((long long)__builtin_amdgcn_s_memrealtime() - nl_r0); \
+        atomicAdd(&nl_probe_cycles[6], nl_w); atomicMax(&nl_probe_cycles[7], nl_w); } } while (0)
 #else
 #define NL_T0() do {} while (0)
 #define NL_T(slot) do {} while (0)
@@ -194,6 +197,77 @@ __device__ float coop_select_small(float *a, int left, int right, int k)
     return res;
 }
 
+// The same for a range of 64 ... 128 elements, two per lane: x0 = positions 0 .. 63 of the range, x1 = 64 .. 127.
+// Ranks run through both registers (v_mbcnt takes the first register's count as its base); a pass swaps at most
+// 64 pairs (2 s <= 128) and only ranks below s are ever fetched, so one 64-lane rank table per side is enough:
+// candidates of rank >= 63 aim at the trash lane with everything that is no candidate.  (s = 64 needs the rank-63
+// entry: possible only with all 128 positions in range -- the function then returns false before it has changed
+// anything and the caller runs that one pass through LDS.)  Leaves through coop_select_small once fewer than 64
+// elements are in range.  *res = the selected element; [left, right] is updated by nothing: the result is final.
+__device__ bool coop_select_mid(float *a, int left, int right, int k, float *res)
+{
+    const int lane = threadIdx.x;
+    int lo = 0, hi = __builtin_amdgcn_readfirstlane(right - left);                    // 63 ... 127
+    const int top = hi;
+    const int target = __builtin_amdgcn_readfirstlane(k) - 1;
+    float x0 = a[left + lane];
+    float x1 = lane + 64 <= top ? a[left + 64 + lane] : 0.0f;
+    constexpr int kTrashLane = 63;
+    bool complete = true;
+    while (hi - lo >= 63) {                                  // (then lo <= 64, hi >= 63)
+        const int pm = (lo + hi) >> 1;
+        const float xs = (pm & 64) ? x1 : x0;
+        const float pivot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), pm & 63));
+        const unsigned long long in0 = lo < 64 ? ~0ull << lo : 0ull;               // (lo = 64: the 64 elements of x1)
+        const unsigned long long in1 = hi >= 64 ? ~0ull >> (127 - hi) : 0ull;
+        const unsigned long long ml0 = ballot64(x0 >= pivot) & in0, ml1 = ballot64(x1 >= pivot) & in1;
+        const unsigned long long mr0 = ballot64(x0 <= pivot) & in0, mr1 = ballot64(x1 <= pivot) & in1;
+        const bool isl0 = __builtin_amdgcn_inverse_ballot_w64(ml0), isl1 = __builtin_amdgcn_inverse_ballot_w64(ml1);
+        const bool isr0 = __builtin_amdgcn_inverse_ballot_w64(mr0), isr1 = __builtin_amdgcn_inverse_ballot_w64(mr1);
+        const int nl0 = __popcll(ml0), nr1 = __popcll(mr1), nr = nr1 + (int)__popcll(mr0);
+        // L-candidates below / R-candidates above each position
+        const int rl0 = below64(ml0);
+        const int rl1 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ml1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ml1, (unsigned)nl0));
+        const int ra1 = nr1 - below64(mr1) - (isr1 ? 1 : 0);
+        const int ra0 = nr - below64(mr0) - (isr0 ? 1 : 0);
+        const unsigned long long sl0 = ml0 & ballot64(ra0 > rl0), sl1 = ml1 & ballot64(ra1 > rl1);
+        const unsigned long long sr0 = mr0 & ballot64(rl0 > ra0), sr1 = mr1 & ballot64(rl1 > ra1);
+        const int s_cnt = (int)__popcll(sl0) + (int)__popcll(sl1);
+        if (s_cnt > 63) { complete = false; break; }
+        const int al0 = min(rl0, kTrashLane) * 4, al1 = min(rl1, kTrashLane) * 4;    // rank as a crossbar address
+        const int ar0 = min(ra0, kTrashLane) * 4, ar1 = min(ra1, kTrashLane) * 4;
+        const int vr_a = __builtin_amdgcn_ds_permute(isr0 ? ar0 : kTrashLane * 4, __float_as_int(x0));
+        const int vr_b = __builtin_amdgcn_ds_permute(isr1 ? ar1 : kTrashLane * 4, __float_as_int(x1));
+        const int vl_a = __builtin_amdgcn_ds_permute(isl0 ? al0 : kTrashLane * 4, __float_as_int(x0));
+        const int vl_b = __builtin_amdgcn_ds_permute(isl1 ? al1 : kTrashLane * 4, __float_as_int(x1));
+        const int val_r = lane < nr1 ? vr_b : vr_a;          // lane t: a[R_t] (the candidates of x1 come first from the right)
+        const int val_l = lane < nl0 ? vl_a : vl_b;          // lane t: a[L_t]
+        const int fr0 = __builtin_amdgcn_ds_bpermute(al0, val_r), fr1 = __builtin_amdgcn_ds_bpermute(al1, val_r);
+        const int fl0 = __builtin_amdgcn_ds_bpermute(ar0, val_l), fl1 = __builtin_amdgcn_ds_bpermute(ar1, val_l);
+        // r = max(R_s, L_{s-1})
+        const int rs0 = first_lane(mr0 & ballot64(ra0 == s_cnt));
+        const int rs1 = first_lane(mr1 & ballot64(ra1 == s_cnt));
+        const int lp0 = first_lane(ml0 & ballot64(rl0 == s_cnt - 1));
+        const int lp1 = first_lane(ml1 & ballot64(rl1 == s_cnt - 1));
+        const int r = max(max(rs0, rs1 < 0 ? -1 : rs1 + 64), max(lp0, lp1 < 0 ? -1 : lp1 + 64));
+        int xi0 = __float_as_int(x0), xi1 = __float_as_int(x1);
+        xi0 = __builtin_amdgcn_inverse_ballot_w64(sl0) ? fr0 : xi0;
+        xi0 = __builtin_amdgcn_inverse_ballot_w64(sr0) ? fl0 : xi0;
+        xi1 = __builtin_amdgcn_inverse_ballot_w64(sl1) ? fr1 : xi1;
+        xi1 = __builtin_amdgcn_inverse_ballot_w64(sr1) ? fl1 : xi1;
+        x0 = __int_as_float(xi0);
+        x1 = __int_as_float(xi1);
+        if (target <= r) hi = r; else lo = r + 1;
+    }
+    if (!complete) return false;                             // (first pass of a 128-element range: nothing has moved)
+    a[left + lane] = x0;
+    if (lane + 64 <= top) a[left + 64 + lane] = x1;
+    lds_fence();
+    if (lo < hi) *res = coop_select_small(a, left + lo, left + hi, target - lo + 1);
+    else         *res = a[left + lo];
+    return true;
+}
+
 // qsort.go:94-126 on a[0..n), k 1-based; all control values are wave-uniform.
 //
 // One Hoare partition pass (qsort.go:100-114) done by the whole wave at once.
@@ -212,20 +286,13 @@ __device__ float coop_select(float *a, unsigned short *lpos, unsigned short *rfw
 {
     const int lane = threadIdx.x;
     int left = 0, right = n - 1;
-#ifdef NL_PROBE
-    long long pt0 = (long long)__builtin_readcyclecounter();
-#endif
     while (left < right) {
         if (right - left < 63) {
-#ifdef NL_PROBE
-            const long long pt1 = (long long)__builtin_readcyclecounter();
-            const float rs = coop_select_small(a, left, right, k);
-            const long long pt2 = (long long)__builtin_readcyclecounter();
-            if (threadIdx.x == 0) { atomicAdd(&nl_probe_cycles[5], (unsigned long long)(pt1 - pt0)); atomicAdd(&nl_probe_cycles[6], (unsigned long long)(pt2 - pt1)); }
-            return rs;
-#else
             return coop_select_small(a, left, right, k);
-#endif
+        }
+        if (right - left <= 127) {
+            float res;
+            if (coop_select_mid(a, left, right, k, &res)) return res;
         }
         const float pivot = a[(left + right) >> 1];
         // classify, and list the misplaced positions in scan order
@@ -301,23 +368,14 @@ __device__ float coop_select_median(float *a, unsigned short *lpos, unsigned sho
 // W: weighted variants (stack.go:442-531, 710-829).  The weights live in their own column and
 // follow only the clip swaps -- quickselect permutes the samples, NOT the weights
 // (stack.go:487), and the weighted mean pairs them index by index all the same.
-//
-// BLK: pixels per work item of a replay over the WHOLE tile (no list).  With BLK = 1 a wave gathers its pixel
-// straight from HBM, 4 bytes out of every line it touches: the weighted 128-frame stack fetched 13 x its
-// algorithmic bytes and, once the decision pass had removed the chains, ran at the speed of those fetches
-// (2.9 TB/s of mostly unused lines).  With BLK = 16 a wave first stages the columns of 16 consecutive pixels
-// in LDS -- every frame contributes one 64-byte segment, four of them per load instruction -- and replays
-// them one after the other from there: the frames are read once.
-template <bool WINSOR, bool W, int BLK>
-__global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
+template <bool WINSOR, bool W>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void stack_sigma_coop_kernel(StackArgs p)
 {
     extern __shared__ float a[];
     float *wz = a + p.n_frames;                   // winsorized copy (WINSOR only)
     float *wt = a + (WINSOR ? 2 : 1) * p.n_frames;          // weights (W only)
     unsigned short *lpos = reinterpret_cast<unsigned short *>(a + ((WINSOR ? 2 : 1) + (W ? 1 : 0)) * p.n_frames);   // partition scratch, 2 x n_frames x 16 bit
     unsigned short *rfwd = lpos + p.n_frames;
-    float *blk = a + ((WINSOR ? 2 : 1) + (W ? 1 : 0) + 1) * p.n_frames;      // BLK > 1: [pixel][frame], odd row length
-    const int NP = p.n_frames | 1;
     const int lane = threadIdx.x;
     const int N = p.n_frames;
     int64_t limit = p.npix;
@@ -349,51 +407,51 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
     // measured).  XCD x takes the x-th eighth of every sweep instead: neighbours run side by side under one L2.
     int64_t wg = blockIdx.x;
     if (!p.list && (gridDim.x & 7u) == 0u) wg = (int64_t)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    if constexpr (BLK > 1) limit = (p.npix + BLK - 1) / BLK;          // (never with a list)
+    // The first 128 frames of a pixel are gathered up front (two loads in flight), its decided rounds and their
+    // bounds come with them (lane r holds round r), the weights of those frames sit in registers.
+    constexpr int PF = 2;
+    const bool dense = p.list == nullptr;
+    float wreg[PF] = {0.0f, 0.0f};
+    if constexpr (W) {
+#pragma unroll
+        for (int c = 0; c < PF; c++) wreg[c] = c * 64 + lane < N ? p.weights[c * 64 + lane] : 0.0f;
+    }
     for (int64_t item = first + wg; item < limit; item += gridDim.x) {
-      int in_item = 1;
-      int64_t pix0 = item;
-      if constexpr (BLK > 1) {
-        static_assert(BLK == 16, "the staging loop maps 16 lanes to the pixels of a block");
-        pix0 = item * BLK;
-        in_item = (int)min((int64_t)BLK, p.npix - pix0);
-        lds_fence();
-        const int j = lane & 15;
-        const float *src = p.frames + pix0 + (j < in_item ? j : 0);
-        float *dst = blk + j * NP;
-        for (int k0 = lane >> 4; k0 < N; k0 += 32) {              // 4 frames per instruction, 8 instructions in flight
-            float v[8];
+        const int64_t pix = dense ? item : (int64_t)p.list[item];
+        float cur[PF];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int k = k0 + 4 * u;
-                v[u] = k < N ? src[(int64_t)k * p.stride] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int k = k0 + 4 * u;
-                if (k < N) dst[k] = v[u];
-            }
+        for (int c = 0; c < PF; c++) {
+            const int k = c * 64 + lane;
+            cur[c] = k < N ? p.frames[pix + (int64_t)k * p.stride] : __builtin_nanf("");
         }
-      } else if (p.list) {
-        pix0 = (int64_t)p.list[item];
-      }
-      for (int j = 0; j < in_item; j++) {
-        const int64_t pix = pix0 + j;
+        const int decided = p.nrounds ? (int)p.nrounds[pix] : 0;
+        float2 bd = make_float2(0.0f, 0.0f);                  // lane r: the bounds of round r
+        if (decided > 0 && lane < kBoundRounds) bd = p.bounds[(size_t)lane * (size_t)p.npix + (size_t)pix];
         const float *fr = p.frames + pix;
         NL_T0();
         lds_fence();
         // ---- gather in frame order, NaN dropped (stack.go:380-387) ----
         int n = 0;
-        for (int base = 0; base < N; base += 64) {
+#pragma unroll
+        for (int c = 0; c < PF; c++) {
+            if (c * 64 < N) {
+                const float x = cur[c];
+                const bool valid = x == x;
+                const unsigned long long m = ballot64(valid);
+                const int pos = n + below64(m);
+                if (valid) a[pos] = x;
+                if (W && valid) wt[pos] = wreg[c];                    // stack.go:452-459
+                n += __popcll(m);
+            }
+        }
+        for (int base = PF * 64; base < N; base += 64) {
             const int k = base + lane;
-            float x = __builtin_nanf("");
-            if constexpr (BLK > 1) { if (k < N) x = blk[j * NP + k]; }
-            else                   { if (k < N) x = fr[(int64_t)k * p.stride]; }
+            const float x = k < N ? fr[(int64_t)k * p.stride] : __builtin_nanf("");
             const bool valid = x == x;
             const unsigned long long m = ballot64(valid);
             const int pos = n + below64(m);
             if (valid) a[pos] = x;
-            if (W && valid) wt[pos] = p.weights[k];                   // stack.go:452-459
+            if (W && valid) wt[pos] = p.weights[k];
             n += __popcll(m);
         }
         lds_fence();
@@ -404,7 +462,6 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
         // bounds of this pixel's first `decided` rounds are on record -- those rounds only permute (the quickselect of
         // QSelectMedian) and clip.  An unweighted result is the mean of the LAST round, which is never on record.
         int rnd = 0;
-        const int decided = p.nrounds ? (int)p.nrounds[pix] : 0;
         if (n > 0) {
             for (;;) {
                 float lo, hi, mean = 0.0f;
@@ -412,9 +469,8 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
                     (void)coop_select(a, lpos, rfwd, n, (n >> 1) + 1);      // qsort.go:70 (the even-n scan of :73-81 does not permute)
                     lds_fence();
                     NL_T(1);
-                    const float2 bd = p.bounds[(size_t)rnd * (size_t)p.npix + (size_t)pix];
-                    lo = bd.x;
-                    hi = bd.y;
+                    lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bd.x), rnd));
+                    hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bd.y), rnd));
                 } else {
                 const float median = coop_select_median(a, lpos, rfwd, n);
                 lds_fence();
@@ -506,7 +562,6 @@ __global__ __launch_bounds__(64) void stack_sigma_coop_kernel(StackArgs p)
         }
         if (lane == 0) p.out[pix] = res;
         NL_T(4);
-      }
     }
     NL_TFLUSH();
     if (lane == 0) {
@@ -570,26 +625,12 @@ int coop_supported(int mode, bool weighted, int n_frames)
     return (n_frames <= 65535 && (size_t)n_frames * coop_columns(mode, weighted) * sizeof(float) <= 64 * 1024) ? 1 : 0;
 }
 
-// dense replays of stacks up to kCoopBlockMaxFrames stage 16 pixels at a time (16 x n_frames x 4 bytes of LDS on top)
-constexpr int kCoopBlock = 16, kCoopBlockMaxFrames = 256;
-
 template <bool WINSOR, bool W>
 static hipError_t launch_coop(const StackArgs &args, int grid, size_t lds, hipStream_t stream, const char **name)
 {
-    static const int forced = getenv("NL_COOP_BLOCK") ? atoi(getenv("NL_COOP_BLOCK")) : -1;     // development switch
-    if (forced == kCoopBlock && !args.list && args.n_frames <= kCoopBlockMaxFrames && args.npix >= 64 * kCoopBlock) {
-        const int64_t blocks = (args.npix + kCoopBlock - 1) / kCoopBlock;
-        int g = (int)(blocks < (int64_t)grid ? blocks : (int64_t)grid);
-        if (g > 8) g &= ~7;                              // whole sweeps for the XCD-contiguous mapping
-        *name = WINSOR ? (W ? "stack_sigma_coop_kernel<true, true, 16>" : "stack_sigma_coop_kernel<true, false, 16>")
-                       : (W ? "stack_sigma_coop_kernel<false, true, 16>" : "stack_sigma_coop_kernel<false, false, 16>");
-        const size_t staged = lds + (size_t)kCoopBlock * (size_t)(args.n_frames | 1) * sizeof(float);
-        hipLaunchKernelGGL((stack_sigma_coop_kernel<WINSOR, W, kCoopBlock>), dim3(g), dim3(64), staged, stream, args);
-    } else {
-        *name = WINSOR ? (W ? "stack_sigma_coop_kernel<true, true, 1>" : "stack_sigma_coop_kernel<true, false, 1>")
-                       : (W ? "stack_sigma_coop_kernel<false, true, 1>" : "stack_sigma_coop_kernel<false, false, 1>");
-        hipLaunchKernelGGL((stack_sigma_coop_kernel<WINSOR, W, 1>), dim3(grid), dim3(64), lds, stream, args);
-    }
+    *name = WINSOR ? (W ? "stack_sigma_coop_kernel<true, true>" : "stack_sigma_coop_kernel<true, false>")
+                   : (W ? "stack_sigma_coop_kernel<false, true>" : "stack_sigma_coop_kernel<false, false>");
+    hipLaunchKernelGGL((stack_sigma_coop_kernel<WINSOR, W>), dim3(grid), dim3(64), lds, stream, args);
     return hipGetLastError();
 }
 

@@ -24,6 +24,7 @@ with StackHandle(n, 4096, rows, device=0) as st:
     st.run_async(mode, 3.0, 3.0, 0.0); st.finish()
     lib.nl_debug_probe(buf, 1)
     npix = 4096 * rows
-    names = ["gather", "select(decided)", "select+chains(undecided)", "clip", "final", "of the selects: LDS-mode passes", "register-mode passes"]
+    names = ["gather", "select(decided)", "select+chains(undecided)", "clip", "final", "whole wave", "whole wave (100 MHz ticks)"]
     print("mode %d frames %d rows %d weighted %d: %s  kernel %.3f ms %s" % (mode, n, rows, weighted,
           "  ".join("%s %.0f" % (nm, buf[i] / npix) for i, nm in enumerate(names)), st.last_kernel_ms, st.last_kernel_name))
+    print("  average waves in flight %.0f, shader clock %.2f GHz, longest wave %.3f ms" % (buf[6] / 1e8 / (st.last_kernel_ms * 1e-3), buf[5] / (buf[6] / 1e8) / 1e9, buf[7] / 1e5))

@@ -862,7 +862,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         h->last_has_counters = true;
         h->last_used_fast = true;
     } else if ((h->exact_flavour == 3 ||
-                (!h->force_exact && weighted &&
+                (!h->force_exact && weighted && !(h->dev_flags & 16u) &&
                  a.n_frames <= (mode == NL_ST_WINSOR_SIGMA ? nl::kTileMaxFramesWinsor : nl::kTileMaxFramesSigma))) &&
                nl::tile_supported(mode, weighted, a.n_frames)) {
         // bit-exact replay over the whole tile, 64 consecutive pixels per wave with their columns in
@@ -879,8 +879,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
         h->last_has_counters = true;
     } else if ((h->exact_flavour == 4 ||
-                (!h->force_exact && weighted && a.n_frames <= 512 &&
-                 (mode == NL_ST_WINSOR_SIGMA || a.n_frames <= nl::kCoop4MaxFramesSigma))) &&
+                (!h->force_exact && weighted && !(h->dev_flags & 8u) && mode == NL_ST_WINSOR_SIGMA &&
+                 a.n_frames >= nl::kCoop4MinFrames && a.n_frames <= nl::kCoop4MaxFrames)) &&
                nl::coop4_supported(mode, weighted, a.n_frames)) {
         // the four-pixels-per-wave replay over the whole tile: weighted stacks of medium depth (the sequential sums
         // are a large share of a dense replay, and a row of 16 lanes wastes fewer of them on short ranges);

@@ -318,10 +318,12 @@ def test_tile_replay_heavy_clipping_and_degenerate_bounds(nl, oracle):
 
 def test_weighted_clip_modes_default_dispatch(nl):
     # each depth runs the replay engine that measured fastest over a whole tile (stack_kernels.h): 64 pixels per
-    # wave, then four pixels per wave, then (sigma) one pixel per wave
+    # wave for shallow stacks, one pixel per wave behind the decision pass (33 ... 128 frames) and for deep
+    # sigma stacks, four pixels per wave for winsorized stacks of 129 ... 200 frames
     tile, four, one = "stack_sigma_tile_kernel<", "stack_sigma_coop4_kernel<", "stack_sigma_coop_kernel<"
-    for n, sigma, winsor in ((16, tile, tile), (44, tile, tile), (45, tile, four), (56, tile, four), (57, four, four),
-                             (96, four, four), (120, four, four), (128, one, four), (300, one, four)):
+    for n, sigma, winsor in ((16, tile, tile), (32, tile, tile), (33, tile, one), (44, tile, one), (45, one, one),
+                             (96, one, one), (128, one, one), (129, one, four), (200, one, four), (201, one, one),
+                             (300, one, one)):
         with nl.StackHandle(n, 64, 4) as st:
             st.fill_synthetic(1)
             st.set_weights(np.linspace(0.2, 1.0, n).astype(np.float32))

@@ -912,7 +912,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
             const char *ignored = "";
             NL_HIP(nl::launch_stack_sigma_decide(a, h->stream, mode == NL_ST_WINSOR_SIGMA, &ignored));
         }
-        const int g = dense_grid(a.npix, 65536, h->width, 1);
+        const int per_item = mode == NL_ST_MEDIAN ? 1 : nl::coop_group(a);
+        const int g = dense_grid(a.npix / per_item, 65536, h->width, per_item);
         if (mode == NL_ST_MEDIAN) NL_HIP(nl::launch_stack_median_coop(a, (int)g, h->stream, &h->last_kernel));
         else                      NL_HIP(nl::launch_stack_sigma_coop(mode, a, (int)g, h->stream, &h->last_kernel));
         NL_HIP(hipEventRecord(h->ev_dom1, h->stream));

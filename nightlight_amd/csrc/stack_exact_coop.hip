@@ -18,6 +18,7 @@
 // The pixel's column lives in LDS as a plain array (n_frames floats per wave;
 // the winsorized variant keeps its clamped copy in a second one).
 #include "stack_kernels.h"
+#include <stdint.h>
 #include <stdlib.h>
 
 namespace nl {
@@ -368,7 +369,13 @@ __device__ float coop_select_median(float *a, unsigned short *lpos, unsigned sho
 // W: weighted variants (stack.go:442-531, 710-829).  The weights live in their own column and
 // follow only the clip swaps -- quickselect permutes the samples, NOT the weights
 // (stack.go:487), and the weighted mean pairs them index by index all the same.
-template <bool WINSOR, bool W>
+//
+// GROUP = 4: a replay over the whole tile (no list) whose work items are four consecutive pixels.  A lane loads
+// the samples of all four at once (16 bytes: the 128 frames x 4 pixels sit in eight registers per lane) and the
+// pixels are replayed one after the other.  One pixel at a time fetched 13 x the algorithmic bytes (4 bytes out
+// of every 64-byte sector, with 16 MB of lines in flight per XCD against 4 MB of L2) and the replay ran at the
+// speed of those fetches.
+template <bool WINSOR, bool W, int GROUP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void stack_sigma_coop_kernel(StackArgs p)
 {
     extern __shared__ float a[];
@@ -416,13 +423,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #pragma unroll
         for (int c = 0; c < PF; c++) wreg[c] = c * 64 + lane < N ? p.weights[c * 64 + lane] : 0.0f;
     }
+    if constexpr (GROUP > 1) limit = p.npix / GROUP;          // (never with a list; npix is a multiple of GROUP)
     for (int64_t item = first + wg; item < limit; item += gridDim.x) {
-        const int64_t pix = dense ? item : (int64_t)p.list[item];
+      float4 grp[PF];
+      if constexpr (GROUP > 1) {
+        static_assert(GROUP == 4, "one 16-byte load per lane and chunk");
+#pragma unroll
+        for (int c = 0; c < PF; c++) {
+            const int k = min(c * 64 + lane, N - 1);          // (frames past the stack are masked below)
+            grp[c] = *reinterpret_cast<const float4 *>(p.frames + item * GROUP + (int64_t)k * p.stride);
+        }
+      }
+      for (int j = 0; j < GROUP; j++) {
+        const int64_t pix = GROUP > 1 ? item * GROUP + j : (dense ? item : (int64_t)p.list[item]);
         float cur[PF];
 #pragma unroll
         for (int c = 0; c < PF; c++) {
             const int k = c * 64 + lane;
-            cur[c] = k < N ? p.frames[pix + (int64_t)k * p.stride] : __builtin_nanf("");
+            if constexpr (GROUP > 1) {
+                const float x = j == 0 ? grp[c].x : j == 1 ? grp[c].y : j == 2 ? grp[c].z : grp[c].w;
+                cur[c] = k < N ? x : __builtin_nanf("");
+            } else {
+                cur[c] = k < N ? p.frames[pix + (int64_t)k * p.stride] : __builtin_nanf("");
+            }
         }
         const int decided = p.nrounds ? (int)p.nrounds[pix] : 0;
         float2 bd = make_float2(0.0f, 0.0f);                  // lane r: the bounds of round r
@@ -562,6 +585,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
         if (lane == 0) p.out[pix] = res;
         NL_T(4);
+      }
     }
     NL_TFLUSH();
     if (lane == 0) {
@@ -625,12 +649,27 @@ int coop_supported(int mode, bool weighted, int n_frames)
     return (n_frames <= 65535 && (size_t)n_frames * coop_columns(mode, weighted) * sizeof(float) <= 64 * 1024) ? 1 : 0;
 }
 
+// whole-tile replays take four pixels per work item when the 16-byte loads are aligned (nlstack_api.hip sizes the grid
+// with the same predicate)
+int coop_group(const StackArgs &args)
+{
+    const bool ok = args.list == nullptr && args.npix % 4 == 0 && args.stride % 4 == 0 && args.npix >= 1024 &&
+                    (reinterpret_cast<uintptr_t>(args.frames) & 15u) == 0;
+    return ok ? 4 : 1;
+}
+
 template <bool WINSOR, bool W>
 static hipError_t launch_coop(const StackArgs &args, int grid, size_t lds, hipStream_t stream, const char **name)
 {
-    *name = WINSOR ? (W ? "stack_sigma_coop_kernel<true, true>" : "stack_sigma_coop_kernel<true, false>")
-                   : (W ? "stack_sigma_coop_kernel<false, true>" : "stack_sigma_coop_kernel<false, false>");
-    hipLaunchKernelGGL((stack_sigma_coop_kernel<WINSOR, W>), dim3(grid), dim3(64), lds, stream, args);
+    if (coop_group(args) == 4) {
+        *name = WINSOR ? (W ? "stack_sigma_coop_kernel<true, true, 4>" : "stack_sigma_coop_kernel<true, false, 4>")
+                       : (W ? "stack_sigma_coop_kernel<false, true, 4>" : "stack_sigma_coop_kernel<false, false, 4>");
+        hipLaunchKernelGGL((stack_sigma_coop_kernel<WINSOR, W, 4>), dim3(grid), dim3(64), lds, stream, args);
+    } else {
+        *name = WINSOR ? (W ? "stack_sigma_coop_kernel<true, true, 1>" : "stack_sigma_coop_kernel<true, false, 1>")
+                       : (W ? "stack_sigma_coop_kernel<false, true, 1>" : "stack_sigma_coop_kernel<false, false, 1>");
+        hipLaunchKernelGGL((stack_sigma_coop_kernel<WINSOR, W, 1>), dim3(grid), dim3(64), lds, stream, args);
+    }
     return hipGetLastError();
 }
 

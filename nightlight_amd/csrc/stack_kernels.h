@@ -210,6 +210,7 @@ hipError_t launch_stack_sigma_ml(const StackArgs &args, const FastArgs &fargs, h
 int coop_supported(int mode, bool weighted, int n_frames);
 hipError_t launch_stack_median_coop(const StackArgs &args, int grid, hipStream_t stream, const char **name);
 hipError_t launch_stack_sigma_coop(int mode, const StackArgs &args, int grid, hipStream_t stream, const char **name);
+int coop_group(const StackArgs &args);      // pixels per work item of that launch (4: whole-tile replay with aligned 16-byte loads)
 
 // ---- stack_exact_coop4.hip (the same replay, four pixels per wave on 16-lane rows: the sequential sums cost a
 // third of the instructions per pixel) ----

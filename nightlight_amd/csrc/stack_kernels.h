@@ -223,15 +223,16 @@ hipError_t launch_stack_sigma_coop4(int mode, const StackArgs &args, int grid, h
 // ms per 512 x 4096 pixels, tile / four pixels per wave / one pixel per wave -- sigma: 40 frames 1.54 / 2.16 / 2.79,
 // 56 frames 2.82 / 2.84 / 3.17, 64 frames 3.5 / 2.9 / 3.2; winsorized: 40 frames 4.37 / 5.22 / 8.11, 48 frames
 // 5.34 / 5.28 / 8.25, 56 frames 6.70 / 6.27 / 8.54)
-constexpr int kTileMaxFramesSigma = 44, kTileMaxFramesWinsor = 32;
+constexpr int kTileMaxFramesSigma = 40, kTileMaxFramesWinsor = 32;
 // (those numbers are from before the decision pass.  With it -- 33 ... 128 frames: the register-resident kernel decides
 // every round, the replay only permutes -- the one-pixel-per-wave replay needs no sequential sums any more and, with
 // its partition passes in registers, wins wherever the decision pass exists, whole 4096^2 images in ms: sigma 36
 // frames 9.3 (tile) vs 11.5, 44: 13.7 vs 13.7, 56: 21.7 vs 16.9, 64: 21.2 (four pixels per wave) vs 18.9, 96: 30.6
-// vs 26.0; winsorized 36 frames 27.2 (tile) vs 16.6, 44: 36.2 vs 17.4, 96: 35.5 (four) vs 28.9, 128: 52.6 vs 38.3.)
-// Four pixels per wave stays for winsorized stacks beyond the decision pass, 129 ... kCoop4MaxFrames (160 frames:
-// 78 vs 93 ms per 2048 x 4096 pixels; 256 frames: 190 vs 132).
-constexpr int kCoop4MinFrames = 129, kCoop4MaxFrames = 200;
+// vs 26.0; winsorized 36 frames 27.2 (tile) vs 16.6, 44: 36.2 vs 17.4, 96: 35.5 (four) vs 28.9, 128: 52.6 vs 38.3;
+// with four pixels per work item (stack_exact_coop.hip, GROUP): sigma 34 frames 8.5 (tile) vs 11.1, 40: 11.4 vs 11.7,
+// 44: 13.7 vs 12.0.)  Four pixels per wave stays for winsorized stacks beyond the decision pass, 129 ...
+// kCoop4MaxFrames (ms per 2048 x 4096 pixels: 136 frames 65 vs 89, 160: 79 vs 93, 192: 115 vs 98).
+constexpr int kCoop4MinFrames = 129, kCoop4MaxFrames = 176;
 int tile_supported(int mode, bool weighted, int n_frames);
 hipError_t launch_stack_sigma_tile(int mode, const StackArgs &args, int grid, hipStream_t stream, const char **name);
 

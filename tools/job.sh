@@ -1,5 +1,5 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-python tests/sweeps/fuzz_parity.py 4000 97 2>&1 | tail -1
+python -m pytest tests -m gpu -x -q 2>&1 | tail -1
 for m in 2 3; do python bench.py --weighted --mode $m --steps 5 --warmup 2 --no-cpu --no-also 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'; done
-python bench.py --weighted --frames 64 --steps 3 --warmup 1 --no-cpu --no-also 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
-python bench.py --weighted --frames 256 --steps 3 --warmup 1 --no-cpu --no-also 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
+python bench.py --weighted --frames 64 --height 512 --steps 3 --warmup 1 --no-cpu --no-also 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
+python bench.py --weighted --frames 128 --height 512 --steps 3 --warmup 1 --no-cpu --no-also 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
+python bench.py --weighted --frames 600 --height 512 --steps 2 --warmup 1 --no-cpu --no-also 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'

@@ -798,7 +798,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         int grid0 = kCoopGrid, grid1 = kCoopGrid / 4;
         if (h->fb_hint) {
             const int want = next_pow2((int)(2u * (h->fb_hint - 1u) + 64u));
-            grid0 = want < 1024 ? 1024 : (want > kCoopGrid ? kCoopGrid : want);
+            grid0 = want < 1024 ? 1024 : (want > kCoopGrid ? kCoopGrid : want);      // (a 256-workgroup floor measured the same)
             grid1 = grid0 / 4 < 512 ? 512 : grid0 / 4;
         }
         // NL_COOP4=1 (developer switch): replay the lists four pixels per wave (stack_exact_coop4.hip).  Its
@@ -913,11 +913,11 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
             NL_HIP(nl::launch_stack_sigma_decide(a, h->stream, mode == NL_ST_WINSOR_SIGMA, &ignored));
         }
         const int per_item = mode == NL_ST_MEDIAN ? 1 : nl::coop_group(a);
-        // at least 64 work items per workgroup, 8 192 ... 65 536 workgroups: 262 144 single-wave workgroups take 14 ms
-        // to launch on their own, while 8 192 long-lived ones drift apart and stop sharing the sectors they fetch
-        // (64 frames x 512 rows: 2.65 ms with 8 192 workgroups, 6.6 with 65 536; 128 frames x 4096 rows: 36.3 / 29.8 ms)
+        // many short workgroups: neighbours that start together share the sectors they fetch, long-lived workgroups
+        // drift apart (128 frames x 4096^2, weighted sigma: 34.7 ms with 8 192 workgroups, 31.6 with 16 384, 28.0 with
+        // 65 536, 27.2 with 262 144; a 512-row tile of 64 frames: 2.50 / 2.26 / 2.07 / 2.08 ms)
         const int64_t items = a.npix / per_item;
-        const int64_t most = items / 64 < 8192 ? 8192 : (items / 64 > 65536 ? 65536 : items / 64);
+        const int64_t most = 262144;
         const int g = dense_grid(items, most, h->width, per_item);
         if (mode == NL_ST_MEDIAN) NL_HIP(nl::launch_stack_median_coop(a, (int)g, h->stream, &h->last_kernel));
         else                      NL_HIP(nl::launch_stack_sigma_coop(mode, a, (int)g, h->stream, &h->last_kernel));

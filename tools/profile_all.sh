@@ -22,5 +22,9 @@ timeout 300 $P median512 --mode 0 --frames 512
 timeout 300 $P mad128 --mode 4
 timeout 300 $P mean128 --mode 1
 timeout 300 $P wsigma128 --weighted
+timeout 300 $P wwinsor128 --weighted --mode 3
+timeout 300 $P sigma384 --frames 384
+timeout 300 $P sigma160 --frames 160
+timeout 300 $P sigma100 --frames 100
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 tail -c 400 gpurun_out/bench_default.json

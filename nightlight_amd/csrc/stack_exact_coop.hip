@@ -546,29 +546,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 rnd++;
                 NL_T(2);
 
-                // stack.go:411-424: swap-with-last, re-test the same index
+                // stack.go:411-424: swap-with-last, re-test the same index.  The loop fills every clipped position below
+                // the new length m = n - c (a "hole") with a surviving sample from positions >= m, and it takes those from
+                // the right end: a clipped sample that arrives in a hole is clipped again on the re-test and replaced by
+                // the next one.  There are as many survivors at or behind m as holes in front of it, so the i-th hole from
+                // the left receives the i-th survivor from the right -- all moves at once instead of two barriers per
+                // clipped sample; the two counters count every clipped sample once either way (low tested first).
                 const int before = n;
-                int j = 0;
-                while (j < n) {
-                    int found = -1;
-                    for (int base = j; base < n; base += 64) {
+                {
+                    int c = 0, c_low = 0;
+                    for (int base = 0; base < n; base += 64) {
                         const int idx = base + lane;
                         const float x = idx < n ? a[idx] : 0.0f;
-                        const bool clipped = idx < n && (x < lo || x > hi);
-                        const unsigned long long m = ballot64(clipped);
-                        if (m) { found = base + __builtin_ctzll(m); break; }
+                        const bool low = idx < n && x < lo;
+                        const bool clipped = idx < n && (low || x > hi);
+                        c += __popcll(ballot64(clipped));
+                        c_low += __popcll(ballot64(low));
                     }
-                    if (found < 0) break;
-                    const float g = a[found];
-                    const float last = a[n - 1];
-                    float last_w = 0.0f;
-                    if (W) last_w = wt[n - 1];
-                    if (g < lo) c_lo++; else c_hi++;
-                    lds_fence();
-                    if (lane == 0) { a[found] = last; if (W) wt[found] = last_w; }
-                    lds_fence();
-                    n--;
-                    j = found;
+                    c_lo += c_low;
+                    c_hi += c - c_low;
+                    if (c > 0) {
+                        const int m = n - c;
+                        int nf = 0;                                      // survivors at [m, n), listed from the left
+                        for (int base = m & ~63; base < n; base += 64) {
+                            const int idx = base + lane;
+                            const bool in = idx >= m && idx < n;
+                            const float x = in ? a[idx] : 0.0f;
+                            const bool fill = in && !(x < lo || x > hi);
+                            const unsigned long long mf = ballot64(fill);
+                            if (fill) rfwd[nf + below64(mf)] = (unsigned short)idx;
+                            nf += __popcll(mf);
+                        }
+                        lds_fence();
+                        int nh = 0;                                      // holes at [0, m), from the left
+                        for (int base = 0; base < m; base += 64) {
+                            const int idx = base + lane;
+                            const float x = idx < m ? a[idx] : 0.0f;
+                            const bool hole = idx < m && (x < lo || x > hi);
+                            const unsigned long long mh = ballot64(hole);
+                            if (hole) {
+                                const int src = (int)rfwd[nf - 1 - (nh + below64(mh))];
+                                a[idx] = a[src];
+                                if (W) wt[idx] = wt[src];
+                            }
+                            nh += __popcll(mh);
+                        }
+                        lds_fence();
+                        n = m;
+                    }
                 }
                 NL_T(3);
                 if (n == before || n <= 1) {

@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=0,
                     help="rows of the stack timed on the CPU (0 = auto, about 3 s per run)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--preheat-steps", type=int, default=64,
+                    help="untimed passes in front of the W warm-up steps (the same number on every rank): a box fresh from idle "
+                         "runs its first ~30 ms of work at a lower clock and 5 warm-up passes are 9 ms -- measured 1.91 ms per pass "
+                         "with --steps 5 --warmup 2, 1.81 with 10 / 3, 1.76 with 20 / 5, 1.74 from 100 passes on; reported in config")
     ap.add_argument("--no-also", action="store_true",
                     help="default workload only: skip the 32- and 512-frame stacks reported under \"also\"")
     ap.add_argument("--weighted", action="store_true",
@@ -232,6 +236,9 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize()
 
+        for _ in range(args.preheat_steps):                  # device clock ramp, untimed (see --preheat-steps)
+            step()
+        fence()
         for _ in range(warmup):
             step()
         fence()
@@ -292,7 +299,7 @@ def main():
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
-                       "frames": n, "width": w, "image_rows": image_rows, "rows_per_gpu": rows, "mode": args.mode,
+                       "frames": n, "width": w, "image_rows": image_rows, "rows_per_gpu": rows, "mode": args.mode, "preheat_steps": args.preheat_steps,
                        "sharding": "row tiles, %d rank(s); per pass one all-reduce of 2 int64 clip counters%s"
                                    % (world, " on the device (RCCL, the pass's own stream)" if (world > 1 and on_device)
                                       else ""),

@@ -26,7 +26,7 @@ python "$repo/tools/profile_summary.py" stats "$(find "$out/${tag}_stats" -name 
 for counters in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU"; do
     name=$(echo "$counters" | tr ' ' '_')
     rocprofv3 --kernel-trace --pmc $counters -d "$out/${tag}_pmc_$name" -o p -- \
-        python "$repo/bench.py" --steps 3 --warmup 1 --no-cpu --no-also "$@" > /dev/null 2> "$out/${tag}_pmc_$name.log"
+        python "$repo/bench.py" --steps 3 --warmup 1 --preheat-steps 0 --no-cpu --no-also "$@" > /dev/null 2> "$out/${tag}_pmc_$name.log"
     db=$(find "$out/${tag}_pmc_$name" -name 'p_results.db' | head -1)
     if [ -n "$db" ]; then python "$repo/tools/profile_summary.py" pmc "$db" >> "$out/${tag}_pmc.txt"; fi
 done

@@ -345,6 +345,34 @@ def test_weighted_modes_match_oracle(nl, oracle, mode, n):
         assert gc == wc
 
 
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("n", [64, 100, 127, 128, 129, 200])
+@pytest.mark.parametrize("width,height", [(64, 32), (65, 17)])
+@pytest.mark.parametrize("engine", [0, 2])          # default dispatch (decision pass + replay up to 128 frames) / the replay alone
+def test_weighted_replay_partition_corner_cases(nl, oracle, mode, n, width, height, engine):
+    # columns chosen for the register partition passes of the wave-per-pixel replay (stack_exact_coop.hip):
+    # descending order (every pair of the first pass swaps: 64 swaps at 128 frames, the one pass that falls back to LDS),
+    # ascending order (no swap at all), all samples equal and two-valued columns (every position a candidate of both
+    # sides), a saw tooth; 64 x 32 pixels go four to a work item, 65 x 17 (odd) one at a time
+    rng = np.random.default_rng(n * 7 + width)
+    k = np.arange(n, dtype=np.float32)[:, None]
+    px = np.arange(width * height, dtype=np.float32)[None, :]
+    base = 1000.0 + 0.25 * px
+    frames = (base + rng.normal(0.0, 30.0, (n, width * height))).astype(np.float32)
+    npix = width * height
+    frames[:, 0::8] = (base - 3.0 * k)[:, 0::8]                       # descending
+    frames[:, 1::8] = (base + 3.0 * k)[:, 1::8]                       # ascending
+    frames[:, 2::8] = np.broadcast_to(base, (n, npix))[:, 2::8]       # all equal
+    frames[:, 3::8] = (base + 50.0 * (k % 2))[:, 3::8]                # two values
+    frames[:, 4::8] = (base + 10.0 * (k % 7) - 4.0 * (k % 3))[:, 4::8]   # saw tooth with ties
+    frames[5 % n, 5::8] = 30000.0                                     # one hot sample: a second round
+    frames = frames.reshape(n, height, width)
+    weights = (0.2 + 0.8 * rng.random(n)).astype(np.float32)
+    got, gc, want, wc = run_both(nl, oracle, mode, frames, width, height, weights, 2.5, 2.5, exact=engine)
+    assert same_values(got, want), "%s weighted n=%d: %s" % (MODES[mode], n, describe_mismatch(got, want))
+    assert gc == wc
+
+
 @pytest.mark.parametrize("mode", [0, 2, 3, 4, 5])
 def test_ties_and_asymmetric_sigmas(nl, oracle, mode):
     width, height = 50, 20

@@ -1,1 +1,1 @@
-python bench.py --steps 20 --warmup 5 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 300 gpurun_out/bench_default.json
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "partition_corner" 2>&1 | tail -5

@@ -161,8 +161,8 @@ int nl_stack_copy_counters_async(nl_stack_t *h, void *device_dst);
  * per lane with the column in LDS, 2 = one wavefront per pixel, 3 = one
  * wavefront per 64 consecutive pixels with their columns in LDS, 4 = four
  * pixels per wavefront on 16-lane rows -- 2, 3 and 4 exist for sigma and
- * winsorized clipping, weighted or not; 3 is what the weighted clip modes run
- * by default up to 64 frames, 4 replays the pixels the fast kernels cannot decide).  Default 0:
+ * winsorized clipping, weighted or not; by default the weighted clip modes run 3
+ * for shallow stacks, a decision pass + 2 for 33 ... 128 frames, 4 or 2 above).  Default 0:
  * sigma clipping uses the register-resident kernel, which keeps the clip
  * counters identical to the reference's and the output within summation-order
  * rounding, and hands undecidable pixels to the exact kernel. */

@@ -1,1 +1,2 @@
-python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "partition_corner" 2>&1 | tail -5
+bash tools/timeline.sh 2>&1 | tail -9 | head -6
+bash tools/timeline.sh --frames 512 2>&1 | tail -9 | head -6

@@ -76,6 +76,7 @@ struct nl_stack {
     // queue many passes without a host sync and read every pass's GPU time afterwards
     hipEvent_t ring_start[kTimingRing] = {}, ring_stop[kTimingRing] = {};
     hipEvent_t ring_dom0[kTimingRing] = {}, ring_dom1[kTimingRing] = {};
+    bool ring_dom0_is_start[kTimingRing] = {};            // the pass recorded one event for both (nothing ran in between)
     int64_t pass_seq = 0;                                  // passes enqueued so far
     int64_t copy_waits_pass = 0;                           // pass the copy stream has been ordered behind
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;      // = the ring slot of the current / last pass
@@ -624,7 +625,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         h->ev_start = h->ring_start[slot]; h->ev_stop = h->ring_stop[slot];
         h->ev_dom0 = h->ring_dom0[slot]; h->ev_dom1 = h->ring_dom1[slot];
     }
-    NL_HIP(hipEventRecord(h->ev_start, h->stream));
+    const bool timed = !(h->dev_flags & 32u);         // developer switch 32: a pass without its timing events
+    if (timed) NL_HIP(hipEventRecord(h->ev_start, h->stream));
     // The sigma / winsorized fast path from 17 frames on (a zonal kernel followed by a generic pass) runs the
     // FUSED protocol (StackArgs::final): no memset in front of the pass -- the previous fused pass's dominant
     // kernel zeroed this pass's scratch set, the two sets alternate -- and no reduction kernel behind it.
@@ -640,6 +642,12 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
     // counts to ONE word, and thousands of workgroups doing that take longer than a reduction kernel)
     const bool fused = fused_on && !(h->dev_flags & 1u) && sigma_fast && a.n_frames > 16 && h->fb_hint != 0 &&
                        h->fb_hint - 1u < kFusedMaxList && nl::coop_supported(mode, weighted, a.n_frames) != 0;
+    // Every event recorded on the pass's stream costs a few microseconds of it (three of them: 17 us of a 277 us pass on
+    // a 512-row tile, tools/wall_probe.py): a fused pass that finds its scratch set clean has nothing between "start" and
+    // "dominant kernel starts", and the event behind the dominant kernel is also the fork of the side stream.
+    const bool one_start = timed && fused && h->sets_clean;
+    h->ring_dom0_is_start[h->pass_seq % kTimingRing] = one_start;
+    if (one_start) h->ev_dom0 = h->ev_start;
     if (fused) {
         if (h->sets_clean) h->cur_set ^= 1;
         else NL_HIP(hipMemsetAsync(h->d_sets, 0, 2 * kScratchBytes, h->stream));
@@ -652,7 +660,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         NL_HIP(hipMemsetAsync(h->d_partial, 0, kScratchBytes, h->stream));
     }
     h->sets_clean = false;                       // until this pass is enqueued completely
-    NL_HIP(hipEventRecord(h->ev_dom0, h->stream));
+    if (timed && !one_start) NL_HIP(hipEventRecord(h->ev_dom0, h->stream));
     if (mode == NL_ST_MEAN) {
         NL_HIP(nl::launch_stack_mean(weighted, a, h->stream, &h->last_kernel));
         NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
@@ -813,7 +821,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
             Fork *k = static_cast<Fork *>(u);
             nl_stack *hh = k->h;
             const char *ignored = "";
-            hipError_t err = hipEventRecord(hh->ev_fork, hh->stream);
+            hipEvent_t fork_ev = (hh->dev_flags & 32u) ? hh->ev_fork : hh->ev_dom1;      // (ev_dom1: recorded just now, behind the dominant kernel)
+            hipError_t err = (hh->dev_flags & 32u) ? hipEventRecord(hh->ev_fork, hh->stream) : hipSuccess;
             if (hh->dev_flags & 2u) {            // developer switch: the first replay in front of the generic pass, same stream
                 nl::StackArgs first = k->e;
                 first.list_snap = k->snap;
@@ -824,7 +833,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
                 k->err = err;
                 return;
             }
-            if (err == hipSuccess) err = hipStreamWaitEvent(hh->side_stream, hh->ev_fork, 0);
+            if (err == hipSuccess) err = hipStreamWaitEvent(hh->side_stream, fork_ev, 0);
             nl::StackArgs first = k->e;
             first.list_snap = k->snap;                    // the list as the dominant kernel left it (snapshot on the device)
             first.list_part = 0;
@@ -834,10 +843,10 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
             k->err = err;
         };
         if (a.n_frames <= 128)
-            NL_HIP(nl::launch_stack_sigma_fast(a, f, h->stream, &h->last_kernel, h->ev_dom1,
+            NL_HIP(nl::launch_stack_sigma_fast(a, f, h->stream, &h->last_kernel, timed ? h->ev_dom1 : nullptr,
                                                mode == NL_ST_WINSOR_SIGMA, after, &fork));
         else   // 129..512 frames: 2 or 4 lanes per pixel
-            NL_HIP(nl::launch_stack_sigma_ml(a, f, h->stream, &h->last_kernel, h->ev_dom1,
+            NL_HIP(nl::launch_stack_sigma_ml(a, f, h->stream, &h->last_kernel, timed ? h->ev_dom1 : nullptr,
                                              mode == NL_ST_WINSOR_SIGMA, after, &fork));
         NL_HIP(fork.err);
         const char *exact_name = "";
@@ -1047,7 +1056,7 @@ int nl_stack_pass_times(nl_stack_t *h, int back, float *pass_ms, float *dominant
         *pass_ms = ms;
     }
     if (dominant_ms) {
-        NL_HIP(hipEventElapsedTime(&ms, h->ring_dom0[slot], h->ring_dom1[slot]));
+        NL_HIP(hipEventElapsedTime(&ms, h->ring_dom0_is_start[slot] ? h->ring_start[slot] : h->ring_dom0[slot], h->ring_dom1[slot]));
         *dominant_ms = ms;
     }
     return NL_OK;

@@ -1,3 +1,5 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-NL_FUZZ_MODES=2,3 NL_FUZZ_N=30,140 python tests/sweeps/fuzz_parity.py 15000 2024 2>&1 | tail -1
-NL_FUZZ_MODES=2,3 NL_FUZZ_N=120,520 python tests/sweeps/fuzz_parity.py 3000 2025 2>&1 | tail -1
+python -m pytest tests -m gpu -x -q 2>&1 | tail -1
+python tools/wall_probe.py 2 128 512 32
+python tools/wall_probe.py 2 32 4096 32
+python tools/wall_probe.py 2 128 4096 32
+python bench.py --no-cpu --steps 20 --warmup 5 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"kernel_ms": [0-9.]*\|"pass_ms": [0-9.]*' | tr '\n' ' '

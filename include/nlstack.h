@@ -171,7 +171,10 @@ int nl_stack_set_exact(nl_stack_t *h, int on);
  * same either way): bit 0 = plain pass protocol (memset before, reduction kernel after every pass) instead of
  * the fused one, bit 1 = the exact replay of the dominant kernel's hand-overs runs in front of the generic pass
  * on the same stream instead of beside it (kernel traces then show each kernel's own duration), bit 2 = weighted
- * stacks replay every clipping round in full (no decision pass).  Default 0.
+ * stacks replay every clipping round in full (no decision pass), bit 3 (8) = weighted stacks skip the
+ * four-pixels-per-wave replay, bit 4 (16) = they skip the 64-pixels-per-wave tile replay (the next engine of the
+ * table in DESIGN.md section 3 runs), bit 5 (32) = a pass records no timing events (nl_stack_pass_times then reports
+ * stale values; tools/wall_probe.py measures what the events cost).  Default 0.
  * No counterpart in the reference. */
 int nl_stack_set_dev_flags(nl_stack_t *h, unsigned flags);
 /* Pixels of the last pass that were re-done by the exact kernel. */

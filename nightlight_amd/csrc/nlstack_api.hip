@@ -889,7 +889,8 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         h->last_has_counters = true;
     } else if ((h->exact_flavour == 4 ||
                 (!h->force_exact && weighted && !(h->dev_flags & 8u) && mode == NL_ST_WINSOR_SIGMA &&
-                 a.n_frames >= nl::kCoop4MinFrames && a.n_frames <= nl::kCoop4MaxFrames)) &&
+                 a.n_frames >= nl::kCoop4MinFrames && a.n_frames <= nl::kCoop4MaxFrames &&
+                 !(nl::decide_ml_supported(mode, a.n_frames, a.npix) && ensure_bounds(h)))) &&      // (only without a decision pass)
                nl::coop4_supported(mode, weighted, a.n_frames)) {
         // the four-pixels-per-wave replay over the whole tile: weighted stacks of medium depth (the sequential sums
         // are a large share of a dense replay, and a row of 16 lanes wastes fewer of them on short ranges);
@@ -920,6 +921,19 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
             a.nrounds = h->d_nrounds;
             const char *ignored = "";
             NL_HIP(nl::launch_stack_sigma_decide(a, h->stream, mode == NL_ST_WINSOR_SIGMA, &ignored));
+        } else if (weighted && h->exact_flavour == 0 && mode != NL_ST_MEDIAN && nl::decide_ml_supported(mode, a.n_frames, a.npix) &&
+                   ensure_bounds(h)) {
+            // 129 ... 512 frames: the LDS-column kernel of the frame-count class decides (FastArgs::record_only: no
+            // outputs, lists or counters; a pixel it would hand to the generic pass has no round on record)
+            a.bounds = h->d_bounds;
+            a.nrounds = h->d_nrounds;
+            nl::FastArgs f;
+            f.fb_list = nullptr; f.fb_count = nullptr; f.fb_capacity = 0; f.fb_snap = nullptr;
+            f.gen_list = nullptr; f.gen_count = nullptr; f.gen_capacity = 0; f.gen_hint = 0;
+            f.in_list = nullptr; f.in_count = nullptr; f.in_capacity = 0;
+            f.record_only = 1;
+            const char *ignored = "";
+            NL_HIP(nl::launch_stack_sigma_mlz(a, f, h->stream, &ignored, mode == NL_ST_WINSOR_SIGMA));
         }
         const int per_item = mode == NL_ST_MEDIAN ? 1 : nl::coop_group(a);
         // many short workgroups: neighbours that start together share the sectors they fetch, long-lived workgroups

@@ -17,6 +17,11 @@ int fast_mlz_supported(int mode, bool weighted, int n_frames)
     return (n_frames > 128 && n_frames <= 512) ? 1 : 0;
 }
 
+int decide_ml_supported(int mode, int n_frames, int64_t npix)
+{
+    return (fast_mlz_supported(mode, false, n_frames) && npix < kFastMaxPixels) ? 1 : 0;
+}
+
 // the zonal launch over the whole tile (the generic pass over its hand-over list is stack_fast_mlg.hip)
 hipError_t launch_stack_sigma_mlz(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name,
                                   bool winsor)

@@ -444,7 +444,7 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
 
     float res = p.ref_loc;
     int c_lo = 0, c_hi = 0;
-    int rnd = 0;                                           // winsorized: clipping rounds decided so far (StackArgs::bounds)
+    int rnd = 0;                                           // clipping rounds decided so far (StackArgs::bounds)
     int a = 0, b = n;                                      // survivors = sorted ranks [a, b)
     constexpr float kErrF = (float)(2 * L::ROUNDINGS + 8);
 
@@ -640,16 +640,15 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
             if (bail) {
                 to_exact = true;
                 active = false;
-                if constexpr (WINSOR) { if (p.nrounds && role == 0) p.nrounds[pix] = (unsigned char)min(rnd, kBoundRounds); }
+                if (p.nrounds && role == 0) p.nrounds[pix] = (unsigned char)min(rnd, kBoundRounds);
             } else {
-                if constexpr (WINSOR) {
-                    // the thresholds of a decided round go on record: should the pixel turn undecidable later, its
-                    // replay skips the winsorization loop of this round (stack_fast_sigma_impl.hpp)
-                    if (p.bounds) {
-                        if (rnd < kBoundRounds && role == 0)
-                            p.bounds[(size_t)rnd * (size_t)p.npix + (size_t)pix] = make_float2(lo_max, hi_min);
-                        rnd++;
-                    }
+                // the thresholds of a decided round go on record (winsorized passes: should the pixel turn undecidable
+                // later, its replay skips the winsorization loop of this round, stack_fast_sigma_impl.hpp; decision pass
+                // of a weighted stack, FastArgs::record_only: the replay only permutes)
+                if (p.bounds) {
+                    if (rnd < kBoundRounds && role == 0)
+                        p.bounds[(size_t)rnd * (size_t)p.npix + (size_t)pix] = make_float2(lo_max, hi_min);
+                    rnd++;
                 }
                 c_lo += c1;
                 c_hi += d1;
@@ -664,7 +663,9 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     }
 
     // one lane per pixel reports
-    const bool rep = on && role == 0;
+    const bool rec = q.record_only != 0;
+    if (rec && on && role == 0) p.nrounds[pix] = (unsigned char)(to_generic ? 0 : min(rnd, kBoundRounds));
+    const bool rep = on && role == 0 && !rec;
     if (rep && !to_generic && !to_exact) {
         p.out[pix] = res;
         c_lo_total += c_lo;

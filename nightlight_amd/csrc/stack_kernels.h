@@ -69,6 +69,8 @@ struct FastArgs {
     const unsigned *in_list;      // generic pass: list to process (nullptr = the whole tile)
     const unsigned *in_count;
     unsigned in_capacity;
+    int record_only = 0;          // LDS-column kernels as the DECISION pass of a weighted stack (129 ... 512 frames): no outputs, no
+                                  // lists, no counters -- only StackArgs::bounds / nrounds (0 rounds for a pixel they would hand over)
 };
 
 // sets what nl_last_error() returns on this thread (nlstack_api.hip)
@@ -196,6 +198,7 @@ constexpr int kBoundRounds = 8;
 // ---- stack_fast_decide.hip: the register-resident kernels as the DECISION pass of weighted sigma / winsorized
 // stacks (StackArgs::bounds / nrounds); 45..128 frames ----
 int decide_supported(int mode, int n_frames, int64_t npix);
+int decide_ml_supported(int mode, int n_frames, int64_t npix);      // 129 ... 512 frames: the LDS-column kernel of the class, FastArgs::record_only
 hipError_t launch_stack_sigma_decide(const StackArgs &args, hipStream_t stream, bool winsor, const char **name);
 
 // ---- stack_fast_ml.hip (129..512 frames, 2 or 4 lanes per pixel) ----

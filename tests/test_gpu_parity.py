@@ -318,11 +318,11 @@ def test_tile_replay_heavy_clipping_and_degenerate_bounds(nl, oracle):
 
 def test_weighted_clip_modes_default_dispatch(nl):
     # each depth runs the replay engine that measured fastest over a whole tile (stack_kernels.h): 64 pixels per
-    # wave for shallow stacks, one pixel per wave behind the decision pass (33 ... 128 frames) and for deep
-    # sigma stacks, four pixels per wave for winsorized stacks of 129 ... 176 frames
+    # wave for shallow stacks, one pixel per wave behind the decision pass (33 ... 512 frames) and beyond (four
+    # pixels per wave only where a winsorized stack of 129 ... 176 frames has no decision pass: developer switch 4)
     tile, four, one = "stack_sigma_tile_kernel<", "stack_sigma_coop4_kernel<", "stack_sigma_coop_kernel<"
     for n, sigma, winsor in ((16, tile, tile), (32, tile, tile), (33, tile, one), (40, tile, one), (41, one, one),
-                             (96, one, one), (128, one, one), (129, one, four), (176, one, four), (177, one, one),
+                             (96, one, one), (128, one, one), (129, one, one), (176, one, one), (177, one, one), (512, one, one),
                              (300, one, one)):
         with nl.StackHandle(n, 64, 4) as st:
             st.fill_synthetic(1)

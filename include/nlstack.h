@@ -162,7 +162,7 @@ int nl_stack_copy_counters_async(nl_stack_t *h, void *device_dst);
  * wavefront per 64 consecutive pixels with their columns in LDS, 4 = four
  * pixels per wavefront on 16-lane rows -- 2, 3 and 4 exist for sigma and
  * winsorized clipping, weighted or not; by default the weighted clip modes run 3
- * for shallow stacks, a decision pass + 2 for 33 ... 128 frames, 4 or 2 above).  Default 0:
+ * for shallow stacks, a decision pass + 2 for 33 ... 512 frames, 2 above).  Default 0:
  * sigma clipping uses the register-resident kernel, which keeps the clip
  * counters identical to the reference's and the output within summation-order
  * rounding, and hands undecidable pixels to the exact kernel. */

@@ -233,7 +233,8 @@ constexpr int kTileMaxFramesSigma = 40, kTileMaxFramesWinsor = 32;
 // frames 9.3 (tile) vs 11.5, 44: 13.7 vs 13.7, 56: 21.7 vs 16.9, 64: 21.2 (four pixels per wave) vs 18.9, 96: 30.6
 // vs 26.0; winsorized 36 frames 27.2 (tile) vs 16.6, 44: 36.2 vs 17.4, 96: 35.5 (four) vs 28.9, 128: 52.6 vs 38.3;
 // with four pixels per work item (stack_exact_coop.hip, GROUP): sigma 34 frames 8.5 (tile) vs 11.1, 40: 11.4 vs 11.7,
-// 44: 13.7 vs 12.0.)  Four pixels per wave stays for winsorized stacks beyond the decision pass, 129 ...
+// 44: 13.7 vs 12.0.)  Four pixels per wave stays for winsorized stacks WITHOUT a decision pass (since the LDS-column
+// kernels decide 129 ... 512 frames: developer switch 4 or no memory for the bounds), 129 ...
 // kCoop4MaxFrames (ms per 2048 x 4096 pixels: 136 frames 65 vs 89, 160: 79 vs 93, 192: 115 vs 98).
 constexpr int kCoop4MinFrames = 129, kCoop4MaxFrames = 176;
 int tile_supported(int mode, bool weighted, int n_frames);

@@ -4,7 +4,8 @@ Randomised differential test (run on the GPU box): random frame counts, modes, s
 fractions, ties, infinities and tile geometry through the default dispatch of the C ABI against
 the oracle.  Counters must be identical, values bit-exact or within 1e-5 depending on the kernel.
 usage: fuzz_parity.py [cases] [seed]
-NL_FUZZ_N=lo,hi restricts the frame counts, NL_FUZZ_MODES=2,3 the modes (a kernel class under test)."""
+NL_FUZZ_N=lo,hi restricts the frame counts, NL_FUZZ_MODES=2,3 the modes (a kernel class under test),
+NL_FUZZ_WEIGHTED=p sets the share of weighted cases (default 0.25)."""
 import os
 import sys
 import time
@@ -53,7 +54,7 @@ for i in range(cases):
     elif r < 0.15:
         frames[:, : width * height // 3] = np.float32(rng.uniform(-5, 5))   # constant pixels
     weights = None
-    if mode in (1, 2, 3) and rng.random() < 0.25:
+    if mode in (1, 2, 3) and rng.random() < float(os.environ.get("NL_FUZZ_WEIGHTED", "0.25")):
         weights = rng.uniform(0.2, 1.0, n).astype(np.float32)
     ref_loc = float(rng.choice([0.0, 7.5]))
     with StackHandle(n, width, height, row0=row0, rows=rows) as st:

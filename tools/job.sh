@@ -1,3 +1,2 @@
-NL_FUZZ_WEIGHTED=1 NL_FUZZ_MODES=2,3 NL_FUZZ_N=129,512 python tests/sweeps/fuzz_parity.py 5000 5151 2>&1 | tail -2
-NL_FUZZ_WEIGHTED=1 NL_FUZZ_MODES=2,3 NL_FUZZ_N=20,140 python tests/sweeps/fuzz_parity.py 8000 5152 2>&1 | tail -1
-python bench.py --weighted --frames 512 --steps 2 --warmup 1 --preheat-steps 1 --no-cpu --no-also 2>/dev/null | cut -c1-2000 | grep -o '"ms_per_step": [0-9.]*\|"bit_exact": [a-z]*\|"clip_counters_equal": [a-z]*'
+python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+for cap in 0 8 11 14; do echo "cap $cap"; NL_WINSOR_CAP=$cap bash tools/qb.sh "--mode 3 --no-cpu" "--mode 3 --frames 24 --no-cpu" "--mode 3 --frames 64 --no-cpu" "--mode 3 --frames 512 --height 512 --no-cpu" "--mode 3 --frames 300 --height 1024 --no-cpu" | cut -c1-118; done

@@ -330,7 +330,7 @@ __device__ __forceinline__ float nan_to_inf(float x)
 // PADDED = false: the caller knows N == NS (no unused positions).
 template <int NS, int GAP = 16, class SORT = FullSort, bool NT = false, bool PADDED = true>
 __device__ __forceinline__ int gather_sorted(const float *frames, int64_t stride, int N,
-                                             unsigned boff, float (&v)[NS])
+                                             unsigned boff, float (&v)[NS], int lo_pads = 0)
 {
     // Buffer loads: the address is (scalar descriptor base) + (scalar offset) +
     // (one per-lane byte offset), so the 128 loads need neither per-load VGPR
@@ -365,8 +365,11 @@ __device__ __forceinline__ int gather_sorted(const float *frames, int64_t stride
     static_range<P0, NS>([&](auto K) NL_INL {
         constexpr int k = decltype(K)::value;
         const int pad = (N - 1 - k) >> 31;                        // scalar: N is uniform
+        // lo_pads of the unused positions become -Inf instead (they sort FIRST): the zonal kernels of a stack with
+        // many unused positions start with their low pointer behind them, see stack_fast_sigma_impl.hpp
+        const int inf = 0x7f800000 | (((k - N - lo_pads) >> 31) & (int)0x80000000);
         t0 += __int_as_float(__float_as_int(v[k]) & ~pad);
-        v[k] = __int_as_float((__float_as_int(v[k]) & ~pad) | (0x7f800000 & pad));
+        v[k] = __int_as_float((__float_as_int(v[k]) & ~pad) | (inf & pad));
     });
     static_chunks<0, P0 / 4, 8>([&](auto K) NL_INL {
         constexpr int k = 4 * decltype(K)::value;

@@ -640,7 +640,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
                              nl::fast_ml_supported(mode, weighted, a.n_frames, a.npix));
     // (only while the exact list is short -- the length the last finished pass reported: its replays add their
     // counts to ONE word, and thousands of workgroups doing that take longer than a reduction kernel)
-    const bool fused = fused_on && !(h->dev_flags & 1u) && sigma_fast && a.n_frames > 16 && h->fb_hint != 0 &&
+    const bool fused = fused_on && !(h->dev_flags & 1u) && sigma_fast && a.n_frames > 8 && h->fb_hint != 0 &&
                        h->fb_hint - 1u < kFusedMaxList && nl::coop_supported(mode, weighted, a.n_frames) != 0;
     // Every event recorded on the pass's stream costs a few microseconds of it (three of them: 17 us of a 277 us pass on
     // a 512-row tile, tools/wall_probe.py): a fused pass that finds its scratch set clean has nothing between "start" and

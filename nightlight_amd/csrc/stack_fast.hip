@@ -480,7 +480,7 @@ hipError_t launch_stack_mad_fast(const StackArgs &args, const FastArgs &fargs, h
 }
 
 // smallest network size with a zonal instantiation
-constexpr int kZonalMinSize = 24;
+constexpr int kZonalMinSize = 16;
 
 // kernel names as rocprofv3 prints them (template arguments: NS, ZONAL, WINSOR, TIGHT, RECORD)
 template <int NS, bool ZONAL, bool WINSOR, bool TIGHT>

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
     // zone widths: 8 clipped + 8 missing samples per lane for the larger
     // networks, 4 + 4 for the small ones
     constexpr int KZ = NS >= 48 ? kZone : 4, KP = TIGHT ? 0 : (NS >= 48 ? kPadMax : 4);
-    static_assert(!ZONAL || NS >= 24, "zonal passes need room between the zones");
+    static_assert(!ZONAL || NS >= 16, "zonal passes need room between the zones");
     constexpr int ZL = KZ;                                    // low zone  = positions [0, ZL)
     constexpr int ZH = ZONAL ? NS - KZ - KP : NS;             // high zone = positions [ZH, NS)
 
@@ -63,20 +63,29 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         // zonal sigma: only the clip zones and the median window need exact ranks (the
         // winsorized variant also reads single positions in between: full sort)
         constexpr int MW0 = ZONAL ? ZH / 2 - 1 : 0, MW1 = ZONAL ? ZL + NS / 2 + 1 : NS;
-        using Sorter = std::conditional_t<ZONAL && !WINSOR, ZonalSort<ZL, MW0, MW1, ZH>, FullSort>;
+        using Sorter = std::conditional_t<(ZONAL && !WINSOR && NS >= 24), ZonalSort<ZL, MW0, MW1, ZH>, FullSort>;      // (16 positions: nothing to prune)
         float v[NS];
-        const int n = gather_sorted<NS, 16, Sorter, true, !TIGHT>(p.frames, p.stride, N, boff, v);
+        // A stack with only one or two frames more than the next smaller network (17, 18, 25, 26, 33, 34, 49, 50 ...
+        // frames) would keep a single sample or two in the high zone [ZH, NS) -- the rest of it is padding -- and hand every
+        // pixel with a clipped high sample to the generic pass (8 ... 32 % of them, measured: 3 - 5 ms instead of 0.5 - 2).
+        // Some of the padding therefore goes to the BOTTOM as -Inf, where it is what a clipped low sample is: dead
+        // positions in front of the low pointer.  Both zones then hold at least about half their width in samples.
+        int lo_pads = 0;
+        // (plain sigma only: the winsorized kernels decide fewer pixels with it -- 52 frames: 10 825 -> 525 651 on the exact
+        // list, 6.2 -> 18.9 ms -- for a reason not found before the round ended; their cliffs stay: 49 frames 23.7 ms)
+        if constexpr (ZONAL && !TIGHT && !WINSOR) lo_pads = min(max(KZ / 2 + 1 - (N - ZH), 0), KZ / 2 - 1);     // (N is wave-uniform)
+        const int n = gather_sorted<NS, 16, Sorter, true, !TIGHT>(p.frames, p.stride, N, boff, v, lo_pads);
         bool to_exact = false;
 
         float res = p.ref_loc;
         int c_lo = 0, c_hi = 0;
-        int a = 0, b = n;                       // surviving samples = sorted positions [a, b)
+        int a = lo_pads, b = lo_pads + n;       // surviving samples = sorted positions [a, b)
         bool active = on && n > 0;
         bool to_generic = false;
         if constexpr (ZONAL) {
             // zonal passes need b > ZH (and a < ZL): lanes with more missing
             // samples are handed to the generic pass, the others carry on
-            to_generic = active && !(n > ZH);
+            to_generic = active && !(b > ZH);
             active = active && !to_generic;
         }
 
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         // max|x| over the survivors (only enters the reference-mean error term):
         // first pass from the two ends of the sorted column, afterwards from the
         // bounds every survivor passed
-        float amax = fmaxf(fabsf(v[0]), fabsf(pick<ZONAL ? ZH : 0, NS>(v, n - 1)));
+        float amax = fmaxf(fabsf(pick<0, ZONAL ? ZL : 1>(v, a)), fabsf(pick<ZONAL ? ZH : 0, NS>(v, b - 1)));
 
         int rnd = 0;                           // RECORD: clipping rounds decided so far
         if (ZONAL && lane == 0) NL_STAT(4, 1);

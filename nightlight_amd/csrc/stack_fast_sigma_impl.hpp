@@ -71,9 +71,13 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         // Some of the padding therefore goes to the BOTTOM as -Inf, where it is what a clipped low sample is: dead
         // positions in front of the low pointer.  Both zones then hold at least about half their width in samples.
         int lo_pads = 0;
-        // (plain sigma only: the winsorized kernels decide fewer pixels with it -- 52 frames: 10 825 -> 525 651 on the exact
-        // list, 6.2 -> 18.9 ms -- for a reason not found before the round ended; their cliffs stay: 49 frames 23.7 ms)
-        if constexpr (ZONAL && !TIGHT && !WINSOR) lo_pads = min(max(KZ / 2 + 1 - (N - ZH), 0), KZ / 2 - 1);     // (N is wave-uniform)
+        // (winsorized kernels: only for the single frame count right above the smaller network -- 17 / 49 / 113 frames:
+        // 6.0 -> 4.9, 23.7 -> 13.4, 22.7 -> 8.6 ms; two and more frames above it they decide FEWER pixels with the
+        // padding split -- 52 frames: 10 825 -> 525 651 on the exact list, 6.2 -> 18.9 ms -- for a reason not found
+        // before the round ended)
+        if constexpr (ZONAL && !TIGHT) {
+            if (!WINSOR || N - ZH == 1) lo_pads = min(max(KZ / 2 + 1 - (N - ZH), 0), KZ / 2 - 1);     // (N is wave-uniform)
+        }
         const int n = gather_sorted<NS, 16, Sorter, true, !TIGHT>(p.frames, p.stride, N, boff, v, lo_pads);
         bool to_exact = false;
 

@@ -71,12 +71,11 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         // Some of the padding therefore goes to the BOTTOM as -Inf, where it is what a clipped low sample is: dead
         // positions in front of the low pointer.  Both zones then hold at least about half their width in samples.
         int lo_pads = 0;
-        // (winsorized kernels: only for the single frame count right above the smaller network -- 17 / 49 / 113 frames:
-        // 6.0 -> 4.9, 23.7 -> 13.4, 22.7 -> 8.6 ms; two and more frames above it they decide FEWER pixels with the
-        // padding split -- 52 frames: 10 825 -> 525 651 on the exact list, 6.2 -> 18.9 ms -- for a reason not found
-        // before the round ended)
+        // (winsorized kernels too -- 49 / 50 / 113 frames 23.7 / 11.1 / 22.7 -> 6.0 / 6.0 / 8.6 ms -- since the bound on the number of
+        // clamped samples takes the dead positions in front of the low pointer into account, see n_lo below: without that
+        // the padding widened every pixel's interval and 50 times as many went to the exact list)
         if constexpr (ZONAL && !TIGHT) {
-            if (!WINSOR || N - ZH == 1) lo_pads = min(max(KZ / 2 + 1 - (N - ZH), 0), KZ / 2 - 1);     // (N is wave-uniform)
+            lo_pads = min(max(KZ / 2 + 1 - (N - ZH), 0), KZ / 2 - 1);     // (N is wave-uniform)
         }
         const int n = gather_sorted<NS, 16, Sorter, true, !TIGHT>(p.frames, p.stride, N, boff, v, lo_pads);
         bool to_exact = false;
@@ -326,7 +325,12 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                     }
                     float var_l, err_l;
                     {
-                        const float n_lo = (float)min(CS * t_lo + CS - 1, cnt), n_hi = (float)min(CS * t_hi + CS - 1, cnt);
+                        // (the tested positions are k = CS - 1 (mod CS) from below and k = 0 (mod CS) from above, the survivors
+                        // are [a, b): t tested survivors beyond a clamp mean at most CS t + CS - 1 - a % CS, resp.
+                        // CS t + (b - 1) % CS survivors beyond it -- without the remainders every dead position in front
+                        // of the low pointer, clipped or -Inf padding, widened the interval)
+                        const float n_lo = (float)min(CS * t_lo + CS - 1 - (a % CS), cnt);
+                        const float n_hi = (float)min(CS * t_hi + ((b - 1) % CS), cnt);
                         const float dL = (wi.Lp - wi.Lm) * (1.0f + 2.0f * kU), dH = (wi.Hp - wi.Hm) * (1.0f + 2.0f * kU);
                         // ybar = cz + wd_t, off by <= (NS/4+8) u mean|y-c| <= 3e-6 sqrt(E[(y-c)^2]) plus its own rounding
                         const float ybar = cz + wd_t;

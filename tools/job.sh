@@ -1,5 +1,3 @@
 python -m pytest tests -m gpu -x -q 2>&1 | tail -1
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-python tests/sweeps/fuzz_parity.py 30000 9001 2>&1 | tail -1
-python tests/sweeps/parity_sweep.py 2>&1 | tail -1
-python bench.py --steps 20 --warmup 5 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 200 gpurun_out/bench_default.json
+NL_FUZZ_MODES=3 NL_FUZZ_N=9,128 python tests/sweeps/fuzz_parity.py 12000 919 2>&1 | tail -1
+for n in 17 18 49 50 52 60 113 114 120 128; do python tools/ab_flags.py 3 $n 4096 0 4096 1 0 | cut -c1-150; done

@@ -1,6 +1,8 @@
 python -m pytest tests -m gpu -x -q 2>&1 | tail -1
-NL_FUZZ_WEIGHTED=1 NL_FUZZ_MODES=3 NL_FUZZ_N=33,128 python tests/sweeps/fuzz_parity.py 6000 1001 2>&1 | tail -1
-python tests/sweeps/fuzz_parity.py 15000 1002 2>&1 | tail -1
-python tests/sweeps/parity_sweep.py 2>&1 | tail -1
-python bench.py --no-cpu --steps 20 --warmup 5 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"kernel_ms": [0-9.]*' | tr '\n' ' '
-python bench.py --weighted --mode 3 --steps 3 --warmup 1 --no-also 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"bit_exact": [a-z]*\|"clip_counters_equal": [a-z]*' | tr '\n' ' '
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+python bench.py --steps 20 --warmup 5 2>/dev/null | python3 -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        b=json.loads(l); print(b['value'], b['ms_per_step'], b['roofline']['frac'], b['roofline']['pass_frac'], b['cpu_baseline']['parity_with_gpu']['clip_counters_equal'], [ (a['ms_per_step'], a['pass_frac']) for a in b['also']])
+"

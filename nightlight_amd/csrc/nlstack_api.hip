@@ -53,6 +53,7 @@ constexpr int kListGrid = 2048;     // workgroups of the exact kernel in fallbac
 constexpr int kCoopGrid = 16384;    // workgroups (one wave each) of the wave-per-pixel exact replay
 constexpr int kListLanes = 4;       // pixels per wave there: few pixels, keep divergence low
 constexpr unsigned kFusedMaxList = 512;    // exact-list length up to which a pass runs the fused protocol
+constexpr int kMaxChunks = 16;             // pixel ranges of a chunked pass
 // per-pass device scratch, zeroed by one memset (or, in the fused protocol of the sigma / winsorized fast path, by
 // the previous pass's dominant kernel -- two sets alternate): clip accumulators + list lengths + snapshot
 constexpr size_t kScratchBytes = sizeof(unsigned long long) * nl::kScratchWords;
@@ -93,6 +94,7 @@ struct nl_stack {
     unsigned long long *d_sets = nullptr;      // two scratch sets of kScratchWords; d_partial = the current one
     int cur_set = 0;
     bool sets_clean = false;                   // both sets as a fused pass leaves them: the current one used, the other zeroed
+    bool partial_clean = false;                // the current set is all zeros: the last pass's reduction kernel left it so (plain protocol of the sigma fast path)
     unsigned long long *d_partial = nullptr;   // [kClipSlots][2] clip accumulators + 2 words of list lengths
     float2 *d_bounds = nullptr;                // decision pass of weighted stacks: [kBoundRounds][npix] thresholds, lazily allocated
     unsigned char *d_nrounds = nullptr;        // [npix]
@@ -128,6 +130,14 @@ struct nl_stack {
     bool stage_used[kStageSlots] = {false, false, false, false};
     int stage_next = 0;
     bool uploads_pending = false;
+    // chunked passes (sigma / winsorized fast path, see chunk_plan): the dominant kernel runs as a few launches over
+    // consecutive pixel ranges, each range with hand-over lists of its own, and the tail of a range (generic pass,
+    // exact replays) runs on two more streams while the next range's dominant kernel has the device
+    hipStream_t chunk_stream[2] = {nullptr, nullptr};      // [0]: generic pass + replay of its additions, [1]: replay of the dominant kernel's list
+    hipEvent_t ev_chunk[kMaxChunks] = {};                  // behind the dominant kernel of a chunk
+    hipEvent_t ev_chunk_join[2] = {nullptr, nullptr};
+    unsigned *d_chunk_counts = nullptr;                    // [kMaxChunks][4]: exact-list length, generic-list length, snapshot, spare
+    int last_chunks = 0;                                   // chunks of the last pass (0: not chunked)
     int max_grid = 0;
     int last_mode = -1;
     bool last_has_counters = false;
@@ -207,6 +217,13 @@ static int destroy_impl(nl_stack_t *h)
         if (h->ring_dom0[i]) (void)hipEventDestroy(h->ring_dom0[i]);
         if (h->ring_dom1[i]) (void)hipEventDestroy(h->ring_dom1[i]);
     }
+    for (int i = 0; i < 2; i++) {
+        if (h->chunk_stream[i]) { (void)hipStreamSynchronize(h->chunk_stream[i]); (void)hipStreamDestroy(h->chunk_stream[i]); }
+        if (h->ev_chunk_join[i]) (void)hipEventDestroy(h->ev_chunk_join[i]);
+    }
+    for (int i = 0; i < kMaxChunks; i++)
+        if (h->ev_chunk[i]) (void)hipEventDestroy(h->ev_chunk[i]);
+    if (h->d_chunk_counts) (void)hipFree(h->d_chunk_counts);
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -573,6 +590,80 @@ static bool ensure_bounds(nl_stack *h)
     return true;
 }
 
+// Chunked passes (developer switch NL_CHUNKS; off by default, see chunk_plan).  The tail of a sigma / winsorized fast pass -- generic pass, bit-exact replay of the undecidable
+// pixels -- is latency- and gather-bound and depends on the dominant kernel, which is bound by VALU issue: run one after
+// the other they leave each other's resource idle (sigma 512 x 4096^2: 10.6 ms + 0.76 ms).  A chunked pass launches the
+// dominant kernel over a few consecutive pixel ranges; every range has hand-over lists of its own, and its tail runs
+// on two more streams while the next range's dominant kernel has the device.  Only the tail of the LAST range is
+// exposed, so the ranges shrink towards the end.  The plan: per cent of the tile per range (the last takes the rest).
+struct ChunkPlan {
+    int n = 0;
+    int64_t off[kMaxChunks], len[kMaxChunks];
+};
+
+static void chunk_plan(const nl_stack *h, int mode, bool weighted, int n_frames, ChunkPlan *plan)
+{
+    plan->n = 0;
+    // NL_CHUNKS (developer switch): "0" = never, "p1,p2,..." = these ranges whenever the fast path runs
+    static const std::vector<double> env_plan = [] {
+        std::vector<double> v;
+        const char *e = getenv("NL_CHUNKS");
+        if (!e) return v;
+        for (const char *p = e; *p;) {
+            char *end = nullptr;
+            const double x = strtod(p, &end);
+            if (end == p) break;
+            v.push_back(x);
+            p = (*end == ',') ? end + 1 : end;
+            if (*end != ',') break;
+        }
+        if (v.empty()) v.push_back(0.0);
+        return v;
+    }();
+    if (h->dev_flags & 64u) return;                    // developer switch 64: no chunks (A/B inside one process)
+    if (!(mode == NL_ST_SIGMA || mode == NL_ST_WINSOR_SIGMA) || weighted) return;
+    // OFF unless NL_CHUNKS asks for it: measured (round 4), the overlap LOSES -- a replay wave
+    // (64 registers, latency-bound, resident for ~100 us) takes the slot of a dominant-kernel wave (168 registers,
+    // three per SIMD), and the VALU-bound kernel slows down by more than the tail it hides: sigma 512 x 4096^2
+    // 11.47 ms unchunked, 11.97 ms chunked at default stream priority, 13.6 - 14.3 ms with high-priority tails.
+    (void)n_frames;
+    if (env_plan.empty() || (env_plan.size() == 1 && env_plan[0] <= 0.0)) return;
+    const double *pc = env_plan.data();
+    int n = (int)env_plan.size();
+    if (n < 2) return;
+    if (n > kMaxChunks) n = kMaxChunks;
+    int64_t at = 0;
+    for (int k = 0; k < n && at < h->npix; k++) {
+        int64_t len = (int64_t)((double)h->npix * pc[k] / 100.0);
+        len = (len + 1023) & ~(int64_t)1023;           // whole workgroups of every dominant kernel, aligned loads
+        if (len <= 0) continue;
+        if (k == n - 1 || at + len > h->npix) len = h->npix - at;
+        plan->off[plan->n] = at;
+        plan->len[plan->n] = len;
+        plan->n++;
+        at += len;
+    }
+    if (plan->n > 0 && at < h->npix) plan->len[plan->n - 1] += h->npix - at;
+    if (plan->n < 2) plan->n = 0;
+}
+
+static int ensure_chunk_resources(nl_stack *h)
+{
+    if (h->d_chunk_counts) return NL_OK;
+    // the tails get the wave slots the dominant kernel's retiring workgroups free BEFORE its own next workgroups do
+    // (NL_CHUNK_PRIO=0: default priority, for A/B runs)
+    static const bool prio = [] { const char *e = getenv("NL_CHUNK_PRIO"); return !(e && e[0] == '0'); }();
+    int least = 0, greatest = 0;
+    NL_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    for (int i = 0; i < 2; i++) {
+        NL_HIP(hipStreamCreateWithPriority(&h->chunk_stream[i], hipStreamNonBlocking, prio ? greatest : 0));
+        NL_HIP(hipEventCreateWithFlags(&h->ev_chunk_join[i], hipEventDisableTiming));
+    }
+    for (int i = 0; i < kMaxChunks; i++) NL_HIP(hipEventCreateWithFlags(&h->ev_chunk[i], hipEventDisableTiming));
+    NL_HIP(hipMalloc(&h->d_chunk_counts, sizeof(unsigned) * 4 * kMaxChunks));
+    return NL_OK;
+}
+
 static int auto_select_mode(int l)   // stack.go:45-55
 {
     if (l >= 25) return NL_ST_LINEAR_FIT;
@@ -640,7 +731,10 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
                              nl::fast_ml_supported(mode, weighted, a.n_frames, a.npix));
     // (only while the exact list is short -- the length the last finished pass reported: its replays add their
     // counts to ONE word, and thousands of workgroups doing that take longer than a reduction kernel)
-    const bool fused = fused_on && !(h->dev_flags & 1u) && sigma_fast && a.n_frames > 8 && h->fb_hint != 0 &&
+    ChunkPlan plan;
+    if (sigma_fast && a.n_frames > 16 && nl::coop_supported(mode, weighted, a.n_frames) != 0) chunk_plan(h, mode, weighted, a.n_frames, &plan);
+    const bool chunked = plan.n > 1;
+    const bool fused = fused_on && !chunked && !(h->dev_flags & 1u) && sigma_fast && a.n_frames > 8 && h->fb_hint != 0 &&
                        h->fb_hint - 1u < kFusedMaxList && nl::coop_supported(mode, weighted, a.n_frames) != 0;
     // Every event recorded on the pass's stream costs a few microseconds of it (three of them: 17 us of a 277 us pass on
     // a 512-row tile, tools/wall_probe.py): a fused pass that finds its scratch set clean has nothing between "start" and
@@ -656,10 +750,13 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         a.partial = h->d_partial;
         a.final = h->d_counters;
         a.zero_next = h->d_sets + (size_t)(h->cur_set ^ 1) * nl::kScratchWords;
-    } else {
+    } else if (!h->partial_clean) {
         NL_HIP(hipMemsetAsync(h->d_partial, 0, kScratchBytes, h->stream));
     }
     h->sets_clean = false;                       // until this pass is enqueued completely
+    bool zeroed_behind = false;
+    const bool keep_clean = h->partial_clean && mode == NL_ST_MEAN;     // (a mean pass does not touch the scratch set)
+    h->partial_clean = false;
     if (timed && !one_start) NL_HIP(hipEventRecord(h->ev_dom0, h->stream));
     if (mode == NL_ST_MEAN) {
         NL_HIP(nl::launch_stack_mean(weighted, a, h->stream, &h->last_kernel));
@@ -765,6 +862,89 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
         h->last_has_counters = true;
         h->last_used_fast = true;
+    } else if (chunked) {
+        // the sigma / winsorized fast path as a chunked pass (see chunk_plan): plain protocol (the memset above,
+        // sharded clip counters, a reduction kernel at the end), one set of list lengths per chunk
+        int rc = ensure_chunk_resources(h);
+        if (rc != NL_OK) return rc;
+        NL_HIP(hipMemsetAsync(h->d_chunk_counts, 0, sizeof(unsigned) * 4 * kMaxChunks, h->stream));
+        const bool record = mode == NL_ST_WINSOR_SIGMA && a.n_frames > 128 && fused_on && ensure_bounds(h);     // (as the unchunked pass below)
+        static const bool coop4_env = [] { const char *e = getenv("NL_COOP4"); return e && e[0] == '1'; }();
+        const bool coop4 = coop4_env && nl::coop4_supported(mode, weighted, a.n_frames) != 0;
+        struct Fork { nl_stack *h; nl::StackArgs e; int mode; int grid0; bool coop4; hipEvent_t done; hipError_t err; };
+        for (int k = 0; k < plan.n; k++) {
+            const int64_t off = plan.off[k], len = plan.len[k];
+            const double share = (double)len / (double)h->npix;
+            nl::StackArgs ak = a;
+            ak.frames = a.frames + off;
+            ak.out = a.out + off;
+            ak.npix = len;
+            if (record) {
+                ak.bounds = h->d_bounds + (size_t)nl::kBoundRounds * (size_t)off;      // [round][pixel of the chunk]
+                ak.nrounds = h->d_nrounds + off;
+            }
+            unsigned *cc = h->d_chunk_counts + 4 * k;
+            nl::FastArgs f;
+            memset(&f, 0, sizeof f);
+            f.fb_list = h->d_fb_list + off;
+            f.fb_count = cc;
+            f.fb_capacity = (unsigned)len;
+            f.fb_snap = cc + 2;
+            f.gen_list = h->d_gen_list + off;
+            f.gen_count = cc + 1;
+            f.gen_capacity = (unsigned)len;
+            f.gen_hint = h->gen_hint ? (unsigned)((double)(h->gen_hint - 1u) * share * 1.25) + 1u : 0u;
+            nl::StackArgs e = ak;
+            e.list = f.fb_list;
+            e.list_count = cc;
+            e.list_capacity = (unsigned)len;
+            int grid0 = kCoopGrid, grid1 = kCoopGrid / 4;
+            if (h->fb_hint) {
+                const int want = next_pow2((int)(2.0 * share * (double)(h->fb_hint - 1u)) + 64);
+                grid0 = want < 1024 ? 1024 : (want > kCoopGrid ? kCoopGrid : want);
+                grid1 = grid0 / 4 < 512 ? 512 : grid0 / 4;
+            }
+            if (coop4) { grid0 = (grid0 + 3) / 4; grid1 = (grid1 + 3) / 4; }
+            const bool last = k == plan.n - 1;
+            hipEvent_t done = (last && timed) ? h->ev_dom1 : h->ev_chunk[k];
+            Fork fork{h, e, mode, grid0, coop4, done, hipSuccess};
+            nl::AfterDominant after = [](void *u) {
+                // behind the chunk's dominant kernel: its hand-overs are replayed on one stream, the generic pass
+                // (launched by the caller of this callback) and the replay of what it adds run on the other
+                Fork *fk = static_cast<Fork *>(u);
+                nl_stack *hh = fk->h;
+                const char *ignored = "";
+                hipError_t err = hipStreamWaitEvent(hh->chunk_stream[1], fk->done, 0);
+                nl::StackArgs first = fk->e;
+                first.list_snap = const_cast<unsigned *>(fk->e.list_count) + 2;
+                first.list_part = 0;
+                if (err == hipSuccess) err = fk->coop4 ? nl::launch_stack_sigma_coop4(fk->mode, first, fk->grid0, hh->chunk_stream[1], &ignored)
+                                                       : nl::launch_stack_sigma_coop(fk->mode, first, fk->grid0, hh->chunk_stream[1], &ignored);
+                if (err == hipSuccess) err = hipStreamWaitEvent(hh->chunk_stream[0], fk->done, 0);
+                fk->err = err;
+            };
+            const char *name_k = "";
+            if (a.n_frames <= 128)
+                NL_HIP(nl::launch_stack_sigma_fast(ak, f, h->stream, &name_k, done, mode == NL_ST_WINSOR_SIGMA, after, &fork, h->chunk_stream[0]));
+            else
+                NL_HIP(nl::launch_stack_sigma_ml(ak, f, h->stream, &name_k, done, mode == NL_ST_WINSOR_SIGMA, after, &fork, h->chunk_stream[0]));
+            NL_HIP(fork.err);
+            if (k == 0) h->last_kernel = name_k;
+            const char *exact_name = "";
+            e.list_snap = cc + 2;                         // the generic pass's additions
+            e.list_part = 1;
+            if (coop4) NL_HIP(nl::launch_stack_sigma_coop4(mode, e, grid1, h->chunk_stream[0], &exact_name));
+            else       NL_HIP(nl::launch_stack_sigma_coop(mode, e, grid1, h->chunk_stream[0], &exact_name));
+        }
+        for (int i = 0; i < 2; i++) {
+            NL_HIP(hipEventRecord(h->ev_chunk_join[i], h->chunk_stream[i]));
+            NL_HIP(hipStreamWaitEvent(h->stream, h->ev_chunk_join[i], 0));
+        }
+        NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream, h->d_chunk_counts, plan.n, 4));
+        h->last_lists = true;
+        h->last_fused = false;
+        h->last_has_counters = true;
+        h->last_used_fast = true;
     } else if (!h->force_exact && h->d_fb_list &&
                (nl::fast_supported(mode, weighted, a.n_frames, a.npix) || nl::fast_ml_supported(mode, weighted, a.n_frames, a.npix))) {
         // register-resident fast kernel; pixels it cannot decide go to the exact kernel
@@ -865,7 +1045,11 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
             NL_HIP(nl::launch_stack_exact(mode, weighted, e, lanes, kListGrid, lds, h->stream, &exact_name));
         }
         if (fused) h->sets_clean = true;             // (fused implies coop: every kernel of the pass is enqueued)
-        else NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream, h->d_fb_count));
+        else {
+            // (the reduction zeroes the scratch set behind itself: no memset in front of the next pass)
+            NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream, h->d_fb_count, 1, 0, true));
+            zeroed_behind = true;
+        }
         h->last_lists = true;
         h->last_fused = fused;
         h->last_has_counters = true;
@@ -962,8 +1146,10 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         h->last_has_counters = (mode != NL_ST_MEDIAN);
     }
     NL_HIP(hipEventRecord(h->ev_stop, h->stream));
+    h->partial_clean = zeroed_behind || keep_clean;
     if (!fused) h->last_fused = false;
     if (!sigma_fast) h->last_lists = false;
+    h->last_chunks = chunked ? plan.n : 0;
     h->pass_seq++;
     h->last_mode = mode;
     h->pending = true;
@@ -1024,24 +1210,33 @@ int nl_stack_set_dev_flags(nl_stack_t *h, unsigned flags)
     return NL_OK;
 }
 
+// list lengths of the last fast pass: a sigma / winsorized pass leaves them behind its totals (d_counters[2] = exact list |
+// generic list << 32 -- its own counters may be zeroed again by then), the other fast passes keep them in the scratch set
+static int64_t last_list_length(nl_stack_t *h, int which)
+{
+    if (hipSetDevice(h->device) != hipSuccess) return -1;
+    if (h->last_lists) {
+        unsigned long long c = 0;
+        if (hipMemcpyAsync(&c, h->d_counters + 2, sizeof c, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+        return which == 0 ? (int64_t)(c & 0xffffffffull) : (int64_t)(c >> 32);
+    }
+    unsigned c = 0;
+    if (hipMemcpyAsync(&c, h->d_fb_count + which, sizeof c, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+    return (int64_t)c;
+}
+
 int64_t nl_stack_last_fallback_pixels(nl_stack_t *h)
 {
     if (!h || !h->last_used_fast || !h->d_fb_count) return 0;
-    if (hipSetDevice(h->device) != hipSuccess) return -1;
-    unsigned c = 0;
-    if (hipMemcpyAsync(&c, h->d_fb_count, sizeof c, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
-    if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
-    return (int64_t)c;
+    return last_list_length(h, 0);
 }
 
 int64_t nl_stack_last_generic_pixels(nl_stack_t *h)
 {
     if (!h || !h->last_used_fast || !h->d_fb_count || !h->d_gen_list) return 0;
-    if (hipSetDevice(h->device) != hipSuccess) return -1;
-    unsigned c = 0;
-    if (hipMemcpyAsync(&c, h->d_fb_count + 1, sizeof c, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
-    if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
-    return (int64_t)c;
+    return last_list_length(h, 1);
 }
 
 int nl_stack_linfit_stage_counts(nl_stack_t *h, unsigned *counts, int n)

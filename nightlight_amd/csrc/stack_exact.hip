@@ -384,10 +384,13 @@ __global__ __launch_bounds__(64) void stack_exact_kernel(StackArgs p)
     }
 }
 
-__global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned long long *partial,
+// zero_after: the scratch set goes back to all zeros behind the sums -- the clip slots and the two words of list
+// lengths / snapshot behind them (kScratchWords) -- so that the next pass on the handle needs no memset in front
+__global__ __launch_bounds__(256) void reduce_counters_kernel(unsigned long long *partial,
                                                                int n_slots,
                                                                unsigned long long *counters,
-                                                               const unsigned *list_counts)
+                                                               const unsigned *list_counts, int n_lists, int list_stride,
+                                                               int zero_after)
 {
     __shared__ unsigned long long s_lo[256], s_hi[256];
     unsigned long long lo = 0, hi = 0;
@@ -398,6 +401,8 @@ __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned lon
     s_lo[threadIdx.x] = lo;
     s_hi[threadIdx.x] = hi;
     __syncthreads();
+    if (zero_after)
+        for (int i = threadIdx.x; i < 2 * n_slots; i += 256) partial[i] = 0ull;
     for (int off = 128; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) {
             s_lo[threadIdx.x] += s_lo[threadIdx.x + off];
@@ -408,7 +413,12 @@ __global__ __launch_bounds__(256) void reduce_counters_kernel(const unsigned lon
     if (threadIdx.x == 0) {
         counters[0] = s_lo[0];
         counters[1] = s_hi[0];
-        if (list_counts) counters[2] = (unsigned long long)list_counts[0] | ((unsigned long long)list_counts[1] << 32);
+        if (list_counts) {             // (chunked passes keep one pair of list lengths per chunk)
+            unsigned fb = 0, gen = 0;
+            for (int i = 0; i < n_lists; i++) { fb += list_counts[i * list_stride]; gen += list_counts[i * list_stride + 1]; }
+            counters[2] = (unsigned long long)fb | ((unsigned long long)gen << 32);
+        }
+        if (zero_after) { partial[2 * n_slots] = 0ull; partial[2 * n_slots + 1] = 0ull; }
     }
 }
 
@@ -489,11 +499,12 @@ hipError_t launch_stack_exact(int mode, bool weighted, StackArgs &args, int lane
     }
 }
 
-hipError_t launch_reduce_counters(const unsigned long long *partial, int n_blocks,
-                                  unsigned long long *counters, hipStream_t stream, const unsigned *list_counts)
+hipError_t launch_reduce_counters(unsigned long long *partial, int n_blocks,
+                                  unsigned long long *counters, hipStream_t stream, const unsigned *list_counts,
+                                  int n_lists, int list_stride, bool zero_after)
 {
     hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(256), 0, stream, partial, n_blocks,
-                       counters, list_counts);
+                       counters, list_counts, n_lists, list_stride, zero_after ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -436,6 +436,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       }
       for (int j = 0; j < GROUP; j++) {
         const int64_t pix = GROUP > 1 ? item * GROUP + j : (dense ? item : (int64_t)p.list[item]);
+        const float *fr = p.frames + pix;
+        const int64_t fstride = p.stride;
         float cur[PF];
 #pragma unroll
         for (int c = 0; c < PF; c++) {
@@ -444,13 +446,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 const float x = j == 0 ? grp[c].x : j == 1 ? grp[c].y : j == 2 ? grp[c].z : grp[c].w;
                 cur[c] = k < N ? x : __builtin_nanf("");
             } else {
-                cur[c] = k < N ? p.frames[pix + (int64_t)k * p.stride] : __builtin_nanf("");
+                cur[c] = k < N ? fr[(int64_t)k * fstride] : __builtin_nanf("");
             }
         }
         const int decided = p.nrounds ? (int)p.nrounds[pix] : 0;
         float2 bd = make_float2(0.0f, 0.0f);                  // lane r: the bounds of round r
         if (decided > 0 && lane < kBoundRounds) bd = p.bounds[(size_t)lane * (size_t)p.npix + (size_t)pix];
-        const float *fr = p.frames + pix;
         NL_T0();
         lds_fence();
         // ---- gather in frame order, NaN dropped (stack.go:380-387) ----
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
         for (int base = PF * 64; base < N; base += 64) {
             const int k = base + lane;
-            const float x = k < N ? fr[(int64_t)k * p.stride] : __builtin_nanf("");
+            const float x = k < N ? fr[(int64_t)k * fstride] : __builtin_nanf("");
             const bool valid = x == x;
             const unsigned long long m = ballot64(valid);
             const int pos = n + below64(m);

@@ -500,7 +500,7 @@ static inline void keep_first(hipError_t &acc, hipError_t e) { if (acc == hipSuc
 template <int NS, bool WINSOR>
 static hipError_t launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned tile_blocks,
                               hipStream_t stream, const char **name, hipEvent_t dominant_done,
-                              AfterDominant after, void *user)
+                              AfterDominant after, void *user, hipStream_t tail)
 {
     hipError_t err = hipSuccess;
     FastArgs f = fargs;
@@ -521,7 +521,9 @@ static hipError_t launch_pair(const StackArgs &args, const FastArgs &fargs, unsi
         if (dominant_done) keep_first(err, hipEventRecord(dominant_done, stream));
         if (after) after(user);
         // generic pass over the pixels the zonal waves handed over (its length
-        // is only known on the device: fixed grid, grid-stride loop)
+        // is only known on the device: fixed grid, grid-stride loop); chunked passes run it on
+        // a stream of its own (`tail`, ordered behind the dominant kernel by the caller's callback)
+        if (tail) stream = tail;
         f.in_list = fargs.gen_list;
         f.in_count = fargs.gen_count;
         f.in_capacity = fargs.gen_capacity;
@@ -551,30 +553,30 @@ static hipError_t launch_pair(const StackArgs &args, const FastArgs &fargs, unsi
 
 template <bool WINSOR>
 static hipError_t launch_sized(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name,
-                         hipEvent_t dominant_done, AfterDominant after, void *user)
+                         hipEvent_t dominant_done, AfterDominant after, void *user, hipStream_t tail)
 {
     const unsigned blocks = (unsigned)((args.npix + 255) / 256);
     const int n = args.n_frames;
     // network sizes: the frame count rounded up to the next instantiated size;
     // unused positions count as missing samples
-    if (n <= 8)        return launch_pair<8, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else if (n <= 16)  return launch_pair<16, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else if (n <= 24)  return launch_pair<24, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else if (n <= 32)  return launch_pair<32, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else if (n <= 48)  return launch_pair<48, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else if (n <= 64)  return launch_pair<64, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else if (n <= 80)  return launch_pair<80, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else if (n <= 96)  return launch_pair<96, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else if (n <= 112) return launch_pair<112, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
-    else               return launch_pair<128, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user);
+    if (n <= 8)        return launch_pair<8, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
+    else if (n <= 16)  return launch_pair<16, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
+    else if (n <= 24)  return launch_pair<24, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
+    else if (n <= 32)  return launch_pair<32, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
+    else if (n <= 48)  return launch_pair<48, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
+    else if (n <= 64)  return launch_pair<64, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
+    else if (n <= 80)  return launch_pair<80, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
+    else if (n <= 96)  return launch_pair<96, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
+    else if (n <= 112) return launch_pair<112, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
+    else               return launch_pair<128, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
 }
 
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
                                    const char **name, hipEvent_t dominant_done,
-                                   bool winsor, AfterDominant after, void *user)
+                                   bool winsor, AfterDominant after, void *user, hipStream_t tail)
 {
-    hipError_t err = winsor ? launch_sized<true>(args, fargs, stream, name, dominant_done, after, user)
-                            : launch_sized<false>(args, fargs, stream, name, dominant_done, after, user);
+    hipError_t err = winsor ? launch_sized<true>(args, fargs, stream, name, dominant_done, after, user, tail)
+                            : launch_sized<false>(args, fargs, stream, name, dominant_done, after, user, tail);
     keep_first(err, hipGetLastError());
     return err;
 }

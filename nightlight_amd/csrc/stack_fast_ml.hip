@@ -597,7 +597,7 @@ static inline void keep_first(hipError_t &acc, hipError_t e) { if (acc == hipSuc
 
 template <int LPP, bool WINSOR, bool WIDE>
 static hipError_t launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
-                            hipEvent_t dominant_done, AfterDominant after, void *user, const char **mlz_name)
+                            hipEvent_t dominant_done, AfterDominant after, void *user, const char **mlz_name, hipStream_t tail)
 {
     hipError_t err = hipSuccess;
     const unsigned per_wg = 256 / LPP;
@@ -616,6 +616,7 @@ static hipError_t launch_ml(const StackArgs &args, const FastArgs &fargs, hipStr
     }
     if (dominant_done) keep_first(err, hipEventRecord(dominant_done, stream));
     if (after) after(user);
+    if (tail) stream = tail;          // chunked passes: the generic pass on a stream of its own (the callback ordered it)
     f.in_list = fargs.gen_list;
     f.in_count = fargs.gen_count;
     f.in_capacity = fargs.gen_capacity;
@@ -635,7 +636,7 @@ static hipError_t launch_ml(const StackArgs &args, const FastArgs &fargs, hipStr
 
 template <int LPP>
 static hipError_t launch_ml_variant(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name,
-                              hipEvent_t dominant_done, bool winsor, AfterDominant after, void *user)
+                              hipEvent_t dominant_done, bool winsor, AfterDominant after, void *user, hipStream_t tail)
 {
     // tight zones when (almost) every position is used, otherwise the wide variant while the
     // last lane with samples holds more than 8 of them; in the few remaining cases the tight
@@ -652,25 +653,25 @@ static hipError_t launch_ml_variant(const StackArgs &args, const FastArgs &fargs
     static const bool mlz_on = [] { const char *e = getenv("NL_MLZ"); return !(e && e[0] == '0'); }();
     const char **mlz_name = (mlz_on && fast_mlz_supported(winsor ? NL_ST_WINSOR_SIGMA : NL_ST_SIGMA, false, n)) ? name : nullptr;
     if (mlz_name) {            // every frame count 129..512: LDS-column kernel of its class (stack_fast_mlz.hip)
-        if (winsor) return launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user, mlz_name);
-        return launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user, mlz_name);
+        if (winsor) return launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user, mlz_name, tail);
+        return launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user, mlz_name, tail);
     }
     if (winsor) {
-        if (wide) return launch_ml<LPP, true, true>(args, fargs, stream, dominant_done, after, user, nullptr);
-        return launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user, nullptr);
+        if (wide) return launch_ml<LPP, true, true>(args, fargs, stream, dominant_done, after, user, nullptr, tail);
+        return launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user, nullptr, tail);
     }
-    if (wide) return launch_ml<LPP, false, true>(args, fargs, stream, dominant_done, after, user, nullptr);
-    return launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user, nullptr);
+    if (wide) return launch_ml<LPP, false, true>(args, fargs, stream, dominant_done, after, user, nullptr, tail);
+    return launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user, nullptr, tail);
 }
 
 // kernel names as rocprofv3 prints them (template arguments: LPP, ZONAL, WINSOR, WIDE)
 hipError_t launch_stack_sigma_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
                                  const char **name, hipEvent_t dominant_done, bool winsor,
-                                 AfterDominant after, void *user)
+                                 AfterDominant after, void *user, hipStream_t tail)
 {
     hipError_t err = args.n_frames <= 2 * kMlNS
-        ? launch_ml_variant<2>(args, fargs, stream, name, dominant_done, winsor, after, user)
-        : launch_ml_variant<4>(args, fargs, stream, name, dominant_done, winsor, after, user);
+        ? launch_ml_variant<2>(args, fargs, stream, name, dominant_done, winsor, after, user, tail)
+        : launch_ml_variant<4>(args, fargs, stream, name, dominant_done, winsor, after, user, tail);
     keep_first(err, hipGetLastError());
     return err;
 }

@@ -74,6 +74,12 @@ struct MlzLayout {
     // (four lanes per pixel only: with two the full merge is one cross-lane stage and measures 4 % faster)
     static constexpr bool SELECT = FULL && !WINSOR && LPP == 4;
 #endif
+    // PACK: the clipping rounds run in ONE lane per pixel -- one wave for the workgroup's 64 pixels, the others retire
+    // (see the kernel).  Plain sigma clipping only: measured on the winsorized kernels (60 KiB of LDS, two workgroups
+    // per CU) the packed rounds -- 2.6 x fewer instructions -- ran 1 - 4 % SLOWER: their rounds are a chain of dependent
+    // LDS reads, the LPP copies ran side by side on LPP SIMDs, and a workgroup in its rounds still holds its LDS, so the
+    // freed wave slots stay empty (C3 tile 3.95 -> 4.10 ms, winsor 300: 6.53 -> 6.70 ms).
+    static constexpr bool PACK = !WINSOR;
     static constexpr int KE = 32;                               // SELECT: ranks selected per end (>= KL, KH)
     static constexpr int KLS = SELECT ? KE : KL;                // LDS rows of the low column
     static constexpr int GL = KL / 4 + 1, GH = KH / 4 + 1;      // table entries
@@ -83,8 +89,21 @@ struct MlzLayout {
     static constexpr int H0 = NTOP - KH;                        // rank of high-column slot 0
     // LDS rows, one float per pixel each
     // (SELECT stores whole selected runs with per-lane strides: 2 spare rows in front of the window, 8 behind it)
+    // (SELECT: the low column's table sits in the rows of the selected ranks KL .. KE-1, which no round reads.
+    // PS: 8 per-pixel scalars handed from the sorting phase to the rounds phase -- sample count, shift, fixed moments,
+    // the squares taken off again, window flag, innermost ranks outside the columns; they share the rows of the tables,
+    // which the rounds phase builds after it has read them.  32 KiB or less for the sigma kernels: five workgroups
+    // per CU -- a workgroup in its rounds phase is one wave, but holds its LDS.)
+#ifdef NL_MLZ_BIGLDS            // (A/B builds: tables and scalars in rows of their own, 35 KiB)
     static constexpr int XL = 0, XH = XL + KLS, SL1 = XH + KH, SL2 = SL1 + GL, SH1 = SL2 + GL, SH2 = SH1 + GH,
-                         XW = SH2 + GH + (SELECT ? 2 : 0), ROWS = XW + MW + (SELECT ? 8 : 0);
+                         XW = SH2 + GH + (SELECT ? 2 : 0), PS = XW + MW + (SELECT ? 8 : 0), ROWS = PS + 8;
+#else
+    static constexpr int XL = 0, XH = XL + KLS, SL1 = SELECT ? XL + KL : XH + KH, SL2 = SELECT ? XH + KH : SL1 + GL,
+                         SH1 = SL2 + GL, SH2 = SH1 + GH, XW = SH2 + GH + (SELECT ? 2 : 0), ROWS = XW + MW + (SELECT ? 8 : 0),
+                         PS = SL2;
+#endif
+    static_assert(!SELECT || GL <= KLS - KL, "the low table fits behind the low column");
+    static_assert(GL + GH >= 8, "rows for the per-pixel scalars");
     // roundings a term of the moment sums can see: fixed part (4 accumulators + quad adds), tables, assembly
     static constexpr int ROUNDINGS = (NS / 4 + 10 > KH + 4 ? NS / 4 + 10 : KH + 4) + 12;
     static_assert(NTOP % 16 == 0 && NTOP > NT / 2 && NTOP <= NT, "frame-count class");
@@ -221,22 +240,35 @@ __device__ __forceinline__ void select_window(float (&v)[NS], int role, float *c
         t[j] = b;
     });
     float w[16];
+    float kept_min = 0.0f;                                  // LPP == 4: smallest of a lane's kept candidates (its own sign)
     if constexpr (LPP == 4) {
-        run_network<FusedBitonic<CN, 0>, CN>(t);                          // sorted: lanes 0 / 2 ascending lower halves, 1 / 3 ascending -(upper halves)
-        dpp_stage_begin();
-        static_range<0, CN>([&](auto I) NL_INL {
+        // Round 3 sorted a lane's 64 candidates (the bitonic lower half of its pair's 128) completely.  Only their upper
+        // 32 can reach the 16 ranks below the middle of the pixel that this selection is after -- unless a pair of runs
+        // holds fewer than 96 of the 242 samples below the window, 4.5 sigma of its sampling noise -- so the half-cleaner
+        // keeps those (one max per element, a bitonic 32-sequence), the cascade sorts 32 instead of 64 values, and the
+        // stages behind it run over half the positions: 220 instructions less per wave.  Every dropped candidate is at
+        // most the smallest one kept, so "smallest kept <= lowest window value" proves that none of them belongs into
+        // the window (checked below with the runs' ends; a pixel that fails goes to the generic pass as before).
+        constexpr int CK = CN / 2;
+        float keep[CK];
+        static_range<0, CK>([&](auto I) NL_INL {
             constexpr int i = decltype(I)::value;
-            t[i] = min_mirror_n(t[i], t[i]);               // lanes 0, 2: lower 128 of the 256 candidates; 1, 3: -(upper 128)
+            keep[i] = max_raw(t[i], t[i + CK]);
+        });
+        run_network<FusedBitonic<CK, 0>, CK>(keep);        // sorted: lanes 0 / 2 the upper 32 of their lower halves, 1 / 3 the same of -(upper halves)
+        kept_min = keep[0];
+        dpp_stage_begin();
+        static_range<0, CK>([&](auto I) NL_INL {
+            constexpr int i = decltype(I)::value;
+            keep[i] = min_mirror_n(keep[i], keep[i]);      // lanes 0, 2: positions 32 .. 95 of the (bitonic) lower 128 of the 256 candidates; 1, 3: of -(upper 128)
         });
         dpp_stage_begin();
-        // the 64 largest of the (bitonic) lower 128 / of -(upper 128): partner lane ^ 2, mirrored index; of those
-        // (bitonic again) the 32 largest, then the 16 largest
-        float m2[CN / 2];
-        static_range<0, CN / 2>([&](auto I) NL_INL {
+        // the 32 largest of those 64 (a contiguous stretch of a bitonic sequence is bitonic): partner lane ^ 2, mirrored
+        // index; of those (bitonic again) the 16 largest
+        float m2[CK];
+        static_range<0, CK>([&](auto I) NL_INL {
             constexpr int i = decltype(I)::value;
-            const float a = max_swap2(t[CN - 1 - i], t[i]);                     // position i of the 64 largest
-            const float b = max_swap2(t[CN / 2 - 1 - i], t[i + CN / 2]);        // position i + 32
-            m2[i] = max_raw(a, b);
+            m2[i] = max_swap2(keep[CK - 1 - i], keep[i]);
         });
         static_range<0, 16>([&](auto I) NL_INL {
             constexpr int i = decltype(I)::value;
@@ -268,6 +300,13 @@ __device__ __forceinline__ void select_window(float (&v)[NS], int role, float *c
     const float w_first = __int_as_float(quad_bcast<LPP, 0>(__float_as_int(w[2])));
     const float w_last = __int_as_float(quad_bcast<LPP, 1>(__float_as_int(w[6]) ^ (int)0x80000000));
     window_ok = below <= w_first && w_last <= above;
+    if constexpr (LPP == 4) {
+        // ... and no dropped candidate may belong into the window: the smallest kept one of either lane of this parity
+        // (negated samples in the odd lanes) against the window's end on this side
+        const float km = fmaxf(kept_min, dpp_f<kSwap2>(kept_min));
+        const bool ok = km <= (odd ? -w_last : w_first);
+        window_ok = window_ok && quad_or<LPP>(ok ? 0 : 1) == 0;
+    }
 }
 
 // LDS operations of one wave complete in order; the clobber keeps the compiler from moving
@@ -285,11 +324,18 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     __shared__ float lds[L::ROWS * PW];
     fused_prologue_dominant(p);
 
+    // Two phases.  SORTING: LPP lanes per pixel, every wave of the workgroup -- gather, in-lane sort, merge / selection,
+    // columns + median window + the moments between the columns to LDS.  ROUNDS: ONE lane per pixel, i.e. one wave for
+    // the workgroup's 64 pixels (the others retire at the barrier) -- tables, clipping / winsorization rounds, results.
+    // Round 3 ran the rounds in all LPP lanes of a pixel (same values, LPP times the instructions: a round is per-lane
+    // LDS reads at data-dependent rows plus scalar-like arithmetic, nothing the lanes of a pixel could share out);
+    // a fifth (sigma) to a half (winsorized) of the kernel's instructions were those.  The wave that stays is picked
+    // by the workgroup index so that a CU's SIMDs share the rounds evenly.
     const int lane = threadIdx.x & 63;
+    int c_lo_total = 0, c_hi_total = 0;
+    {   // ---- sorting phase ----
     const int role = threadIdx.x % LPP;
     float *col = lds + threadIdx.x / LPP;                  // element r of this pixel: col[r * PW]
-
-    int c_lo_total = 0, c_hi_total = 0;
     const int64_t pix = (int64_t)blockIdx.x * PW + threadIdx.x / LPP;
     const bool on = pix < p.npix;
     int N = p.n_frames;
@@ -365,6 +411,74 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     }
     lds_settle();
 
+    // shift c = first-pass median (any value near the bulk works, DESIGN.md section 5)
+    float c = col[(L::XW + min(max((n >> 1) - W0, 0), L::MW - 1)) * PW];
+    if constexpr (L::SELECT) c = c_sel;
+
+    // ---- moments of the ranks between the columns (never clipped, never clamped) ----
+    // blocks of 8 registers; a block of lane `role` counts if its ranks lie in [KL, H0) (both multiples of 8):
+    // the rest is a column, or padding above the ranks in use
+    if constexpr (!L::SELECT) {
+        float da[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qa[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int off = role * NS - KL;
+        static_chunks<0, NS / 8, 2>([&](auto J) NL_INL {
+            constexpr int j = decltype(J)::value;
+            float d0 = 0.0f, d1 = 0.0f, q0 = 0.0f, q1 = 0.0f;
+            static_range<0, 4>([&](auto U) NL_INL {
+                constexpr int k = 8 * j + 2 * decltype(U)::value;
+                const float e0 = v[k] - c, e1 = v[k + 1] - c;
+                d0 += e0; d1 += e1;
+                q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
+            });
+            const bool inc = (unsigned)(8 * j + off) < (unsigned)(H0 - KL);
+            da[j & 3] += inc ? d0 + d1 : 0.0f;
+            qa[j & 3] += inc ? q0 + q1 : 0.0f;
+        });
+        d_fix = quad_sum<LPP>((da[0] + da[1]) + (da[2] + da[3]));
+        q_fix = quad_sum<LPP>((qa[0] + qa[1]) + (qa[2] + qa[3]));
+    }
+    // rank KL (first above the low column) and rank H0-1 (last below the high column)
+    float x_in_lo = 0.0f, x_in_hi = 0.0f;                 // (only the winsorized rounds look at them)
+    if constexpr (WINSOR) {
+        x_in_lo = bcast_f(std::integral_constant<int, KL / NS>{}, v[KL % NS]);
+        x_in_hi = bcast_f(std::integral_constant<int, (H0 - 1) / NS>{}, v[(H0 - 1) % NS]);
+    }
+    // the pixel's scalars for the rounds phase (every lane of the pixel stores the same values)
+    col[(L::PS + 0) * PW] = __int_as_float(n);
+    col[(L::PS + 1) * PW] = c;
+    col[(L::PS + 2) * PW] = d_fix;
+    col[(L::PS + 3) * PW] = q_fix;
+    col[(L::PS + 4) * PW] = q_cancel;
+    col[(L::PS + 5) * PW] = __int_as_float(window_ok ? 1 : 0);
+    if constexpr (WINSOR) {
+        col[(L::PS + 6) * PW] = x_in_lo;
+        col[(L::PS + 7) * PW] = x_in_hi;
+    }
+    }   // ---- end of the sorting phase ----
+    if constexpr (L::PACK) {
+        __syncthreads();
+        if ((int)(threadIdx.x >> 6) != (int)(blockIdx.x % (L::BLOCK / 64))) return;
+    } else {
+        lds_settle();
+    }
+
+    // ---- rounds phase: PACK: lane = pixel of the workgroup; else every lane of a pixel runs its rounds ----
+    const int role = L::PACK ? 0 : (int)(threadIdx.x % LPP);         // (role 0 reports)
+    const int slot_px = L::PACK ? lane : (int)(threadIdx.x / LPP);
+    float *col = lds + slot_px;
+    const int64_t pix = (int64_t)blockIdx.x * PW + slot_px;
+    const bool on = pix < p.npix;
+    const int n = __float_as_int(col[(L::PS + 0) * PW]);
+    const float c = col[(L::PS + 1) * PW];
+    const float d_fix = col[(L::PS + 2) * PW], q_fix = col[(L::PS + 3) * PW];
+    const float q_cancel = col[(L::PS + 4) * PW];
+    const bool window_ok = __float_as_int(col[(L::PS + 5) * PW]) != 0;
+    float x_in_lo = 0.0f, x_in_hi = 0.0f;
+    if constexpr (WINSOR) {
+        x_in_lo = col[(L::PS + 6) * PW];
+        x_in_hi = col[(L::PS + 7) * PW];
+    }
+
     bool active = on && n > 0;
     // the alive window must keep its ends inside the columns: at most PADS missing samples (SELECT: and the
     // median window must have come out of the runs' middles)
@@ -373,13 +487,7 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     active = active && !to_generic;
     bool to_exact = false;
 
-    // shift c = first-pass median (any value near the bulk works, DESIGN.md section 5)
-    float c = col[(L::XW + min(max((n >> 1) - W0, 0), L::MW - 1)) * PW];
-    if constexpr (L::SELECT) c = c_sel;
-
     // ---- tables: sums from the inner end of each column outwards, every 4th position ----
-    // (read back from LDS: the high column of a stack that does not fill its lanes spans two lanes;
-    // every lane of the pixel runs the same chain and stores the same values)
     {
         float s1 = 0.0f, s2 = 0.0f;
         col[(L::SL1 + KL / 4) * PW] = 0.0f;
@@ -410,35 +518,6 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
             col[(L::SH1 + g + 1) * PW] = s1;
             col[(L::SH2 + g + 1) * PW] = s2;
         });
-    }
-
-    // ---- moments of the ranks between the columns (never clipped, never clamped) ----
-    // blocks of 8 registers; a block of lane `role` counts if its ranks lie in [KL, H0) (both multiples of 8):
-    // the rest is a column, or padding above the ranks in use
-    if constexpr (!L::SELECT) {
-        float da[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qa[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        const int off = role * NS - KL;
-        static_chunks<0, NS / 8, 2>([&](auto J) NL_INL {
-            constexpr int j = decltype(J)::value;
-            float d0 = 0.0f, d1 = 0.0f, q0 = 0.0f, q1 = 0.0f;
-            static_range<0, 4>([&](auto U) NL_INL {
-                constexpr int k = 8 * j + 2 * decltype(U)::value;
-                const float e0 = v[k] - c, e1 = v[k + 1] - c;
-                d0 += e0; d1 += e1;
-                q0 = __builtin_fmaf(e0, e0, q0); q1 = __builtin_fmaf(e1, e1, q1);
-            });
-            const bool inc = (unsigned)(8 * j + off) < (unsigned)(H0 - KL);
-            da[j & 3] += inc ? d0 + d1 : 0.0f;
-            qa[j & 3] += inc ? q0 + q1 : 0.0f;
-        });
-        d_fix = quad_sum<LPP>((da[0] + da[1]) + (da[2] + da[3]));
-        q_fix = quad_sum<LPP>((qa[0] + qa[1]) + (qa[2] + qa[3]));
-    }
-    // rank KL (first above the low column) and rank H0-1 (last below the high column)
-    float x_in_lo = 0.0f, x_in_hi = 0.0f;                 // (only the winsorized rounds look at them)
-    if constexpr (WINSOR) {
-        x_in_lo = bcast_f(std::integral_constant<int, KL / NS>{}, v[KL % NS]);
-        x_in_hi = bcast_f(std::integral_constant<int, (H0 - 1) / NS>{}, v[(H0 - 1) % NS]);
     }
     lds_settle();
 
@@ -690,20 +769,28 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         }
     }
 
-    __shared__ int s_lo[4], s_hi[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         c_lo_total += __shfl_xor(c_lo_total, o, 64);
         c_hi_total += __shfl_xor(c_hi_total, o, 64);
     }
-    if (lane == 0) { s_lo[threadIdx.x >> 6] = c_lo_total; s_hi[threadIdx.x >> 6] = c_hi_total; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int t_lo = 0, t_hi = 0;
-        for (int w = 0; w < L::BLOCK / 64; w++) { t_lo += s_lo[w]; t_hi += s_hi[w]; }
-        unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
-        if (t_lo) atomicAdd(slot + 0, (unsigned long long)t_lo);
-        if (t_hi) atomicAdd(slot + 1, (unsigned long long)t_hi);
+    if constexpr (L::PACK) {
+        if (lane == 0) {                                   // (the one wave of the rounds phase)
+            unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+            if (c_lo_total) atomicAdd(slot + 0, (unsigned long long)c_lo_total);
+            if (c_hi_total) atomicAdd(slot + 1, (unsigned long long)c_hi_total);
+        }
+    } else {
+        __shared__ int s_lo[4], s_hi[4];
+        if (lane == 0) { s_lo[threadIdx.x >> 6] = c_lo_total; s_hi[threadIdx.x >> 6] = c_hi_total; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t_lo = 0, t_hi = 0;
+            for (int w = 0; w < L::BLOCK / 64; w++) { t_lo += s_lo[w]; t_hi += s_hi[w]; }
+            unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+            if (t_lo) atomicAdd(slot + 0, (unsigned long long)t_lo);
+            if (t_hi) atomicAdd(slot + 1, (unsigned long long)t_hi);
+        }
     }
 }
 

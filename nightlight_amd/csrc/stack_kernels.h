@@ -163,10 +163,13 @@ int exact_plan(int mode, bool weighted, int n_frames, int n_pad, int max_lanes, 
                size_t *lds_bytes);
 hipError_t launch_stack_exact(int mode, bool weighted, StackArgs &args, int lanes, int grid,
                               size_t lds_bytes, hipStream_t stream, const char **name);
-// list_counts (optional): {exact-list length, generic-list length} of the pass, left in counters[2] (low | high << 32)
-hipError_t launch_reduce_counters(const unsigned long long *partial, int n_blocks,
+// list_counts (optional): {exact-list length, generic-list length} of the pass, left in counters[2] (low | high << 32);
+// a chunked pass has n_lists such pairs, list_stride words apart, and leaves their sums
+// zero_after: the kernel leaves the scratch set (kScratchWords words at `partial`) zeroed for the next pass
+hipError_t launch_reduce_counters(unsigned long long *partial, int n_blocks,
                                   unsigned long long *counters, hipStream_t stream,
-                                  const unsigned *list_counts = nullptr);
+                                  const unsigned *list_counts = nullptr, int n_lists = 1, int list_stride = 0,
+                                  bool zero_after = false);
 
 // ---- stack_fast.hip ----
 // one-lane register kernels address a group of 4 frames through one buffer descriptor with
@@ -189,9 +192,11 @@ hipError_t launch_stack_sigma_mlg(const StackArgs &args, const FastArgs &fargs, 
 int fast_mlz_supported(int mode, bool weighted, int n_frames);
 hipError_t launch_stack_sigma_mlz(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name,
                                   bool winsor);
+// tail (optional): the stream the generic pass is launched on instead of `stream` -- chunked passes
+// (nlstack_api.hip), whose after_dominant callback orders it behind the dominant kernel
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
                                    const char **name, hipEvent_t dominant_done,
-                                   bool winsor, AfterDominant after_dominant, void *user);
+                                   bool winsor, AfterDominant after_dominant, void *user, hipStream_t tail = nullptr);
 
 // rounds of clip bounds a decision pass records per pixel (pixels that need more are replayed in full)
 constexpr int kBoundRounds = 8;
@@ -207,7 +212,7 @@ hipError_t launch_stack_median_ml(const StackArgs &args, hipStream_t stream, con
 hipError_t launch_stack_mad_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name);
 hipError_t launch_stack_sigma_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
                                  const char **name, hipEvent_t dominant_done, bool winsor,
-                                 AfterDominant after_dominant, void *user);
+                                 AfterDominant after_dominant, void *user, hipStream_t tail = nullptr);
 
 // ---- stack_exact_coop.hip (bit-exact sigma replay, one wave per pixel) ----
 int coop_supported(int mode, bool weighted, int n_frames);

@@ -22,6 +22,12 @@ Prints ONE JSON line on rank 0 (contract in the task description) including
   cpu_baseline the CPU oracle (C restatement of the Go reference) on a bounded
                strip of the same stack: 1 warm-up + median of 3, N separately
                allocated host frames, all host threads.
+  also         the other stack depths of the north star (sigma clipping, 32 and 512 frames) and, on one GPU,
+               the remaining BASELINE.json configurations (C3 tile with its goal-seek, C4, C5) plus winsorized and
+               weighted sigma clipping at 128 frames: same protocol, each with the dominant kernel's fraction, the
+               pass's fraction and a parity flag (a strip of the same stack through the C ABI against the oracle).
+  fresh_handle what ONE OpStack.Apply pays on a new handle (stack.go:131-138: the drop-in creates a handle per Apply):
+               create, first pass without the hints a previous pass leaves, destroy -- wall-clock milliseconds.
 """
 import argparse
 import json
@@ -37,7 +43,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MODE_NAMES = {0: "median", 1: "mean", 2: "sigma-clip", 3: "winsorized sigma-clip",
               4: "MAD sigma-clip", 5: "linear-fit"}
-TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
+TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
 
 
 def parse():
@@ -70,6 +76,9 @@ def parse():
                     help="per-frame weights in [0.2, 1] (the shape of inverse-noise weights, stack.go:246-253)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank path)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="--gpus 1 only: initialise the process group (world size 1) and drive every pass through the "
+                         "device-side counter reduction all the same -- the RCCL code path of the scaling run on one GPU")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses device 0 (needs --backend gloo)")
     return ap.parse_args()
@@ -96,33 +105,34 @@ def cpu_info():
     return model, threads, (len(pairs) or threads)
 
 
-def cpu_baseline(st, args, rows, weights=None):
+def cpu_baseline(st, args, rows, weights=None, frames_n=None, mode=None, width=None):
     """Times the oracle (oracle/nl_oracle.c, a C restatement of the Go reference: same
     batching rule stack.go:134-138, one worker per host thread) on the first `rows` rows:
     frames as N separate host allocations (as fits.Image.Data is), 1 warm-up, median of 3."""
     import numpy as np
     from oracle import oracle
-    n, w = args.frames, args.width
+    n, w = frames_n or args.frames, width or args.width
+    mode = args.mode if mode is None else mode
     frames = [st.download_rows(i, 0, rows).copy() for i in range(n)]      # N separate allocations
     model, threads, physical = cpu_info()
-    ow = None if args.mode in (0, 5) else weights          # median / linear fit take no weights (stack.go:158,188)
+    ow = None if mode in (0, 5) else weights          # median / linear fit take no weights (stack.go:158,188)
     times = []
-    for it in range(4):
+    for it in range(4 if frames_n is None else 1):          # (the extra workloads: one run, parity only)
         t0 = time.perf_counter()
-        rc, res, cl, ch, _ = oracle.stack_apply(args.mode, frames, ow, args.kappa, args.kappa,
+        rc, res, cl, ch, _ = oracle.stack_apply(mode, frames, ow, args.kappa, args.kappa,
                                                 0.0, num_cpu=threads)
         dt = time.perf_counter() - t0
         assert rc == 0
-        if it > 0:
+        if it > 0 or frames_n is not None:
             times.append(dt)
-    dt = sorted(times)[1]
+    dt = sorted(times)[len(times) // 2]
     return {"value": round(rows * w / dt / 1e6, 3), "unit": "Mpixels/s", "cores": threads,
             "hardware_threads": threads, "physical_cores": physical,
             "kind": "port",
             "sample": "first %d rows x %d px x %d frames of the same synthetic stack (N separate host "
                       "allocations), %s, C restatement of the Go reference (no Go toolchain), 1 warm-up + "
                       "median of 3 runs: %.2f s on %d threads (%d physical cores) of %s"
-                      % (rows, w, n, MODE_NAMES[args.mode], dt, threads, physical, model)}, res, (cl, ch)
+                      % (rows, w, n, MODE_NAMES[mode], dt, threads, physical, model)}, res, (cl, ch)
 
 
 def measured_traffic(kernel, args, rows):
@@ -176,12 +186,18 @@ def main():
     device = 0 if args.share_device else local_rank
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        kw = {}
+        if "MASTER_ADDR" not in os.environ:              # --force-dist without a launcher: a one-rank group of its own
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            kw = dict(init_method="tcp://127.0.0.1:%d" % sk.getsockname()[1], rank=0, world_size=1)
+            sk.close()
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device), **kw)
         else:
-            dist.init_process_group(backend=args.backend)
+            dist.init_process_group(backend=args.backend, **kw)
     on_device = args.backend == "nccl"
 
     n, w = args.frames, args.width
@@ -197,10 +213,12 @@ def main():
     # global clip totals (the log line of stack.go:214-218 needs them on every pass)
     totals = torch.zeros(2, dtype=torch.int64, device="cuda" if on_device else "cpu")
 
-    def time_stack(frames, mode, steps, warmup, weights=None):
+    def time_stack(frames, mode, steps, warmup, weights=None, geo=None):
         """One workload on this rank's row tile: `warmup` untimed passes, then exactly `steps` timed ones
-        bracketed by barrier + synchronize.  Returns the handle (still open) and the timings."""
-        st = StackHandle(frames, w, image_rows, row0=row0, rows=rows, device=device)
+        bracketed by barrier + synchronize.  Returns the handle (still open) and the timings.
+        geo = (width, image_rows, row0, rows) of another geometry than the headline's (1-GPU extras)."""
+        gw, gh, gr0, grows = geo or (w, image_rows, row0, rows)
+        st = StackHandle(frames, gw, gh, row0=gr0, rows=grows, device=device)
         st.fill_synthetic()
         if os.environ.get("NL_DEV_FLAGS"):
             st.set_dev_flags(int(os.environ["NL_DEV_FLAGS"]))
@@ -271,6 +289,54 @@ def main():
             cl, ch = int(totals[0].item()), int(totals[1].item())
         return st, {"dt": dt, "pass_ms": pass_ms, "k_ms": k_ms, "timed": timed, "cl": cl, "ch": ch, "sync_ms": sync_ms}
 
+    def strip_parity(frames, mode, geo, weights_, strip_rows, res, cc):
+        """The first strip_rows rows of the tile through the C ABI against the oracle's result `res` / counters `cc`
+        for the same rows: counters must be equal, values within the north star's 1e-5 (bit-exact for every kernel but
+        the register-resident ones)."""
+        gw, gh, gr0, _ = geo
+        with StackHandle(frames, gw, gh, row0=gr0, rows=strip_rows, device=device) as strip:
+            strip.fill_synthetic()
+            strip.set_weights(weights_)
+            strip.run_async(mode, args.kappa, args.kappa, 0.0)
+            gl, gh_ = strip.finish()
+            got = strip.download_rows(-1, 0, strip_rows)
+        ok = ~np.isnan(res) & (res != 0)
+        same_nan = bool(np.array_equal(np.isnan(got), np.isnan(res)))
+        rel = float(np.max(np.abs(got[ok].astype(np.float64) - res[ok]) / np.abs(res[ok]))) if ok.any() else 0.0
+        counted = mode >= 2
+        return {"clip_counters_equal": bool((gl, gh_) == cc) if counted else True,
+                "clip_counters": [int(gl), int(gh_)],
+                "max_rel_err": rel,
+                "bit_exact": bool(np.array_equal(got, res, equal_nan=True)),
+                "within_1e-5": bool(same_nan and rel <= 1e-5)}
+
+    def fresh_handle_cost(st, frames, mode, weights_):
+        """What ONE Apply pays on a new handle (the drop-in creates a handle per Apply, go/stackhip/stack_hip.go): create
+        (device buffers, streams, events), the first pass -- no grid hints from a previous pass, lazily allocated
+        scratch -- and destroy; the frames are the resident ones of `st` (attached, not uploaded again)."""
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        h2 = StackHandle(frames, w, image_rows, row0=row0, rows=rows, device=device)
+        t1 = time.perf_counter()
+        h2.attach_device_frames(st.frames_device_ptr())
+        h2.set_weights(weights_)
+        t2 = time.perf_counter()
+        h2.run_async(mode, args.kappa, args.kappa, 0.0)
+        cl2, ch2 = h2.finish()
+        t3 = time.perf_counter()
+        h2.run_async(mode, args.kappa, args.kappa, 0.0)
+        h2.finish()
+        t4 = time.perf_counter()
+        h2.attach_device_frames(None)
+        h2.close()
+        t5 = time.perf_counter()
+        return {"ms_create": round((t1 - t0) * 1e3, 3), "ms_first_pass_fresh_handle": round((t3 - t2) * 1e3, 3),
+                "ms_second_pass_synchronous": round((t4 - t3) * 1e3, 3), "ms_destroy": round((t5 - t4) * 1e3, 3),
+                "ms_create_destroy": round((t1 - t0 + t5 - t4) * 1e3, 3),
+                "clip_counters": [int(cl2), int(ch2)],
+                "note": "one handle per OpStack.Apply: create + first pass + destroy on frames already resident "
+                        "(uploads excluded); the timed steps above re-use one handle"}
+
     weights = None
     if args.weighted:
         weights = np.array([0.2 + 0.8 * ((k * 37) % 101) / 100.0 for k in range(n)], np.float32)
@@ -301,7 +367,7 @@ def main():
             "config": {"workload": workload,
                        "frames": n, "width": w, "image_rows": image_rows, "rows_per_gpu": rows, "mode": args.mode, "preheat_steps": args.preheat_steps,
                        "sharding": "row tiles, %d rank(s); per pass one all-reduce of 2 int64 clip counters%s"
-                                   % (world, " on the device (RCCL, the pass's own stream)" if (world > 1 and on_device)
+                                   % (world, " on the device (RCCL, the pass's own stream)" if (dist is not None and on_device)
                                       else ""),
                        "clip_low": cl, "clip_high": ch},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -325,26 +391,11 @@ def main():
                 cpu_rows = max(8, min(rows, int(threads * 3 * 5.0e6 / (n * w))))
             cpu_rows = min(cpu_rows, rows)
             base, res, cc = cpu_baseline(st, args, cpu_rows, weights)
-            # parity in the same run: the same strip through the C ABI vs the oracle.
-            # Clip counters must be equal; values within the north star's 1e-5
-            # (bit-exact for every kernel but the register-resident ones).
-            with StackHandle(n, w, image_rows, row0=row0, rows=cpu_rows, device=device) as strip:
-                strip.fill_synthetic()
-                strip.set_weights(weights)
-                strip.run_async(args.mode, args.kappa, args.kappa, 0.0)
-                gl, gh = strip.finish()
-                got = strip.download_rows(-1, 0, cpu_rows)
-            ok = ~np.isnan(res) & (res != 0)
-            same_nan = bool(np.array_equal(np.isnan(got), np.isnan(res)))
-            rel = float(np.max(np.abs(got[ok].astype(np.float64) - res[ok]) / np.abs(res[ok]))) if ok.any() else 0.0
-            base["parity_with_gpu"] = {
-                "clip_counters_equal": bool((gl, gh) == cc),
-                "clip_counters": [int(gl), int(gh)],
-                "max_rel_err": rel,
-                "bit_exact": bool(np.array_equal(got, res, equal_nan=True)),
-                "within_1e-5": bool(same_nan and rel <= 1e-5),
-            }
+            # parity in the same run: the same strip through the C ABI vs the oracle
+            base["parity_with_gpu"] = strip_parity(n, args.mode, (w, image_rows, row0, rows), weights, cpu_rows, res, cc)
             out["cpu_baseline"] = base
+        if world == 1 and dist is None:
+            out["fresh_handle"] = fresh_handle_cost(st, n, args.mode, weights)
 
     st.close()
     # The other stack depths the north star names (4096 x 4096 x {32, 512} fp32, sigma clipping), same protocol
@@ -352,22 +403,53 @@ def main():
     default_workload = (args.frames == 128 and args.mode == 2 and args.width == 4096 and args.height == 4096 and
                         not args.weak and not args.weighted and not args.image_height)
     if default_workload and not args.no_also:
+        w128 = np.array([0.2 + 0.8 * ((k * 37) % 101) / 100.0 for k in range(128)], np.float32)
+        # (tag, frames, mode, weights, geometry (width, image rows, first row, rows) or None = the headline's tile, goal-seek)
+        extras = [("sigma32", 32, 2, None, None, False), ("sigma512", 512, 2, None, None, False)]
+        if world == 1 and dist is None:
+            # the remaining BASELINE.json configurations on one GPU -- C3 as one of its 8 row tiles (rows 1536 ... 2047 of
+            # 512 x 4096 x 4096, winsorized clipping, and the goal-seek of stackfindsigma.go:48-98 on that tile), C4 (linear
+            # fit; the reference's StackLinearFit takes no weights, stack.go:188-189), C5 -- and the two modes whose kernels
+            # differ most from the headline's: winsorized and weighted sigma clipping at 128 frames
+            extras += [("C3 tile (1 of 8 GPUs)", 512, 3, None, (w, 4096, 1536, 512), True),
+                       ("C4", 128, 5, None, None, False),
+                       ("C5", 64, 0, None, (6000, 4000, 0, 4000), False),
+                       ("winsor128", 128, 3, None, None, False),
+                       ("weighted sigma128", 128, 2, w128, None, False)]
         also = []
-        for frames in (32, 512):
-            st2, t2 = time_stack(frames, 2, args.steps, args.warmup)
+        for tag, frames, mode, wts, geo, goal_seek in extras:
+            st2, t2 = time_stack(frames, mode, args.steps, args.warmup, wts, geo)
             if rank == 0:
-                alg = 4.0 * rows * w * (frames + 1)
-                also.append({
-                    "workload": "%d x %dx%d fp32 frames, sigma-clip kappa=%g, rows split over %d GPU(s)" % (
-                        frames, image_rows, w, args.kappa, world),
-                    "value": round(image_rows * w * args.steps / t2["dt"] / 1e6, 3), "unit": "Mpixels/s",
-                    "ms_per_step": round(t2["dt"] * 1e3 / args.steps, 4),
-                    "ms_per_step_synchronous": round(t2["sync_ms"], 4),
-                    "kernel": st2.last_kernel_name, "kernel_ms": round(t2["k_ms"], 4), "pass_ms": round(t2["pass_ms"], 4),
-                    "frac": round(alg / (t2["k_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "pass_frac": round(alg / (t2["pass_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "algorithmic_bytes": alg, "clip_low": t2["cl"], "clip_high": t2["ch"],
-                    "pixels_redone_by_exact_kernel": st2.last_fallback_pixels})
+                gw, gh, gr0, grows = geo or (w, image_rows, row0, rows)
+                alg = 4.0 * grows * gw * (frames + 1)
+                e = {"tag": tag,
+                     "workload": "%s%d x %dx%d fp32 frames, %s%s kappa=%g, rows split over %d GPU(s)" % (
+                         ("rows [%d,%d) of " % (gr0, gr0 + grows)) if geo and grows != gh else "", frames, gh, gw,
+                         MODE_NAMES[mode], " (weighted)" if wts is not None else "", args.kappa, world),
+                     "value": round((grows if geo else image_rows) * gw * args.steps / t2["dt"] / 1e6, 3), "unit": "Mpixels/s",
+                     "ms_per_step": round(t2["dt"] * 1e3 / args.steps, 4),
+                     "ms_per_step_synchronous": round(t2["sync_ms"], 4),
+                     "kernel": st2.last_kernel_name, "kernel_ms": round(t2["k_ms"], 4), "pass_ms": round(t2["pass_ms"], 4),
+                     "frac": round(alg / (t2["k_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                     "pass_frac": round(alg / (t2["pass_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                     "algorithmic_bytes": alg, "clip_low": t2["cl"], "clip_high": t2["ch"],
+                     "pixels_redone_by_exact_kernel": st2.last_fallback_pixels}
+                if mode == 5:
+                    # (the linear fit is a cascade of stages: kernel_ms is its first stage, the pass is what counts)
+                    e["note"] = "kernel_ms = first stage of the cascade (stack_linfit.hip); pass_ms covers all stages"
+                if goal_seek:
+                    t0 = time.perf_counter()
+                    _, gcl, gch, gsl, gsh, gpasses = st2.find_sigmas(mode, 0.5, 0.5, fetch=False)
+                    e["goal_seek"] = {"target_percent": [0.5, 0.5], "passes": gpasses, "sigma_low": gsl, "sigma_high": gsh,
+                                      "clip_low": gcl, "clip_high": gch,
+                                      "total_ms": round((time.perf_counter() - t0) * 1e3, 3)}
+                if world == 1 and not args.no_cpu:
+                    # parity flag: the first rows of the tile through the C ABI against the oracle (one run, all host threads)
+                    prow = min(16, grows)
+                    _, res2, cc2 = cpu_baseline(st2, args, prow, wts, frames_n=frames, mode=mode, width=gw)
+                    e["parity_with_oracle"] = dict(strip_parity(frames, mode, (gw, gh, gr0, grows), wts, prow, res2, cc2),
+                                                   rows_checked=prow)
+                also.append(e)
             st2.close()
         if rank == 0:
             out["also"] = also

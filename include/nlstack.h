@@ -90,6 +90,11 @@ int nl_stack_upload_wait(nl_stack_t *h);
 /* Device address of the planar frame buffer (for in-place producers that
  * already live on the GPU); valid until destroy/attach. */
 void *nl_stack_frames_device_ptr(nl_stack_t *h);
+/* Device memory (bytes) the handle holds right now: the buffers of nl_stack_create plus what passes and upload paths
+ * have allocated since and keep until nl_stack_destroy (e.g. 65 bytes per pixel of the tile for the thresholds of the
+ * weighted clip modes' decision pass).  The reference sizes its batches to host memory (stackbatches.go:121-187); a
+ * caller doing the same for the device reads this.  No counterpart in the reference. */
+int64_t nl_stack_device_bytes(nl_stack_t *h);
 /* Lends an existing device buffer of the same layout instead of the owned
  * one (NULL restores the owned buffer).  The caller keeps it alive. */
 int nl_stack_attach_device_frames(nl_stack_t *h, void *device_frames);
@@ -173,9 +178,12 @@ int nl_stack_set_exact(nl_stack_t *h, int on);
  * on the same stream instead of beside it (kernel traces then show each kernel's own duration), bit 2 = weighted
  * stacks replay every clipping round in full (no decision pass), bit 3 (8) = weighted stacks skip the
  * four-pixels-per-wave replay, bit 4 (16) = they skip the 64-pixels-per-wave tile replay (the next engine of the
- * table in DESIGN.md section 3 runs), bit 5 (32) = a pass records no timing events (nl_stack_pass_times then reports
- * stale values; tools/wall_probe.py measures what the events cost).  Default 0.
- * No counterpart in the reference. */
+ * table in DESIGN.md section 3 runs), bit 5 (32) = a pass records none of its three timing events (start, dominant
+ * kernel start / end; nl_stack_pass_times then fails with NL_ERR_INVALID_ARG for that pass.  The event at the END of a
+ * pass stays: asynchronous uploads order themselves behind it.  tools/wall_probe.py measures what the events cost),
+ * bit 6 (64) = no chunked pass even where the environment variable NL_CHUNKS asks for one,
+ * bit 7 (128) = winsorized passes of 16 ... 128 frames without the winsorization cascade.
+ * Default 0.  No counterpart in the reference. */
 int nl_stack_set_dev_flags(nl_stack_t *h, unsigned flags);
 /* Pixels of the last pass that were re-done by the exact kernel. */
 int64_t nl_stack_last_fallback_pixels(nl_stack_t *h);

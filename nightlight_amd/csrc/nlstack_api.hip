@@ -54,6 +54,13 @@ constexpr int kCoopGrid = 16384;    // workgroups (one wave each) of the wave-pe
 constexpr int kListLanes = 4;       // pixels per wave there: few pixels, keep divergence low
 constexpr unsigned kFusedMaxList = 512;    // exact-list length up to which a pass runs the fused protocol
 constexpr int kMaxChunks = 16;             // pixel ranges of a chunked pass
+// winsorization cascade, "clipping passes : winsorization rounds per pass : regions of the previous stage's list per
+// workgroup" for every stage (the last one runs to the end): measured on 4096^2 -- up to 40 frames
+// 16 / 24 frames 3.68 / 3.94 -> 2.97 / 3.07 ms, 41 ... 96 frames (64: 5.22 -> 4.59 ms); beyond that a continuing stage
+// re-reads every cache line of the stack for an eighth of its pixels and the cascade loses (128 frames: 5.43 -> 5.83 ms)
+constexpr const char *kWinsorPlanShallow = "1:8,1:12:4,2:16:4,0:0:4";
+constexpr const char *kWinsorPlanDeep = "2:12,2:16:8,3:24:4,0:0:4";
+constexpr int kWinsorCascadeMaxFrames = 96;
 // per-pass device scratch, zeroed by one memset (or, in the fused protocol of the sigma / winsorized fast path, by
 // the previous pass's dominant kernel -- two sets alternate): clip accumulators + list lengths + snapshot
 constexpr size_t kScratchBytes = sizeof(unsigned long long) * nl::kScratchWords;
@@ -78,6 +85,7 @@ struct nl_stack {
     hipEvent_t ring_start[kTimingRing] = {}, ring_stop[kTimingRing] = {};
     hipEvent_t ring_dom0[kTimingRing] = {}, ring_dom1[kTimingRing] = {};
     bool ring_dom0_is_start[kTimingRing] = {};            // the pass recorded one event for both (nothing ran in between)
+    bool ring_timed[kTimingRing] = {};                    // the pass in this slot recorded its timing events (not with developer switch 32)
     int64_t pass_seq = 0;                                  // passes enqueued so far
     int64_t copy_waits_pass = 0;                           // pass the copy stream has been ordered behind
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;      // = the ring slot of the current / last pass
@@ -246,14 +254,8 @@ static int create_impl(nl_stack_t *h)
         return fail(NL_ERR_INVALID_ARG, "device %d out of range (have %d)", h->device, ndev);
     NL_HIP(hipSetDevice(h->device));
     NL_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    for (int i = 0; i < kTimingRing; i++) {
-        NL_HIP(hipEventCreate(&h->ring_start[i]));
-        NL_HIP(hipEventCreate(&h->ring_stop[i]));
-        NL_HIP(hipEventCreate(&h->ring_dom0[i]));
-        NL_HIP(hipEventCreate(&h->ring_dom1[i]));
-    }
-    h->ev_start = h->ring_start[0]; h->ev_stop = h->ring_stop[0];
-    h->ev_dom0 = h->ring_dom0[0]; h->ev_dom1 = h->ring_dom1[0];
+    // (the timing events of a ring slot are created by the first pass that uses it: a handle that lives for ONE
+    // Apply -- the cgo drop-in -- creates 4 events instead of 256)
     NL_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     NL_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     NL_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -457,6 +459,39 @@ int nl_stack_download_rows(nl_stack_t *h, int idx, int first_row, int n_rows, fl
     return NL_OK;
 }
 
+// Device memory the handle holds right now: the buffers of nl_stack_create plus everything a pass, an upload path or
+// the stack of stacks has allocated since (decision-pass thresholds, linear-fit cascade lists, accumulator, ingest
+// staging) -- those stay until nl_stack_destroy, so a caller that sizes batches to the device (OpStackBatches,
+// stackbatches.go:121-187 does it for host memory) can see what is left.
+int64_t nl_stack_device_bytes(nl_stack_t *h)
+{
+    if (!h) return 0;
+    const int64_t np = h->npix;
+    int64_t b = 0;
+    if (h->d_frames_owned) b += np * 4 * h->n_capacity;
+    if (h->d_out) b += np * 4;
+    if (h->d_acc) b += np * 4;
+    if (h->d_weights) b += 4 * (int64_t)h->n_capacity;
+    if (h->d_xstat) b += 8 * (int64_t)(h->n_capacity + 1);
+    if (h->d_sets) b += 2 * (int64_t)kScratchBytes;
+    if (h->d_bounds) b += (int64_t)nl::kBoundRounds * np * 8;
+    if (h->d_nrounds) b += np;
+    if (h->d_fb_list) b += np * 4;
+    if (h->d_gen_list) b += np * 4;
+    if (h->d_counters) b += 32;
+    if (h->d_stat_partial) b += 8 * 3 * kStatBlocks;
+    if (h->d_stat_partial_async) b += 8 * 3 * kStatBlocks;
+    const int lanes = h->n_capacity <= 128 ? 1 : h->n_capacity <= 256 ? 2 : 4;
+    for (int i = 0; i < 2; i++) {
+        if (h->d_lf_list[i]) b += np * 4;
+        if (h->d_lf_state[i]) b += np * 16 * lanes;
+    }
+    if (h->d_lf_count) b += 4 * nl::kLinfitStages;
+    if (h->d_chunk_counts) b += 16 * kMaxChunks;
+    b += (int64_t)h->ingest_bytes + (int64_t)h->ingest_async_bytes;
+    return b;
+}
+
 void *nl_stack_frames_device_ptr(nl_stack_t *h) { return h ? h->d_frames : nullptr; }
 void *nl_stack_result_device_ptr(nl_stack_t *h) { return h ? h->d_out : nullptr; }
 int nl_stack_last_mode(nl_stack_t *h) { return h ? h->last_mode : -1; }
@@ -572,8 +607,11 @@ static const nl::LinfitCascade *linfit_cascade(nl_stack_t *h, int lanes_per_pixe
     return out;
 }
 
-// Weighted sigma / winsorized stacks of 45 .. 128 frames run a decision pass in front of the bit-exact replay
-// (stack_fast_decide.hip): scratch for its thresholds.  false: off (NL_WDECIDE=0, allocation failed).
+// Weighted sigma / winsorized stacks of 33 ... 512 frames run a decision pass in front of the bit-exact replay
+// (33 ... 128 frames: stack_fast_decide.hip, 129 ... 512: the LDS-column kernel of the class, record-only), and
+// unweighted winsorized passes above 128 frames put their decided rounds on record for the list replay: scratch for the
+// thresholds, kBoundRounds * 8 + 1 bytes per pixel of the tile (1.1 GB for 4096^2), allocated by the first pass that
+// wants it and held until the handle is destroyed; nl_stack_device_bytes() reports what a handle holds at any time.  false: off (NL_WDECIDE=0, developer switch 4, allocation failed: those passes then run without it).
 static bool ensure_bounds(nl_stack *h)
 {
     static const bool on = [] { const char *e = getenv("NL_WDECIDE"); return !(e && e[0] == '0'); }();
@@ -672,7 +710,36 @@ static int auto_select_mode(int l)   // stack.go:45-55
     return NL_ST_MEAN;
 }
 
+static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_high, float ref_loc);
+
+// A pass that fails half-way (a launch or an event call after the first kernel) must not hand control back with work in
+// flight on the handle's streams and its bookkeeping half-updated: whatever was enqueued is waited for, the scratch
+// sets count as dirty, no list lengths or hints are taken from the broken pass.  The error of the failing call is kept.
 int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_high, float ref_loc)
+{
+    const int rc = run_async_impl(h, mode, sigma_low, sigma_high, ref_loc);
+    if (rc != NL_OK && h && h->stream) {
+        const std::string keep = g_err;
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+        if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
+        for (int i = 0; i < 2; i++)
+            if (h->chunk_stream[i]) (void)hipStreamSynchronize(h->chunk_stream[i]);
+        (void)hipGetLastError();
+        h->sets_clean = false;
+        h->partial_clean = false;
+        h->last_lists = false;
+        h->last_fused = false;
+        h->last_has_counters = false;
+        h->last_used_fast = false;
+        h->last_chunks = 0;
+        h->pending = false;
+        g_err = keep;
+    }
+    return rc;
+}
+
+static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_high, float ref_loc)
 {
     NL_CHECK_HANDLE(h);
     if (mode < NL_ST_MEDIAN || mode > NL_ST_AUTO) return fail(NL_ERR_INVALID_MODE, "invalid stacking mode");
@@ -713,10 +780,17 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
 
     {
         const int slot = (int)(h->pass_seq % kTimingRing);
+        if (!h->ring_start[slot]) {
+            NL_HIP(hipEventCreate(&h->ring_start[slot]));
+            NL_HIP(hipEventCreate(&h->ring_stop[slot]));
+            NL_HIP(hipEventCreate(&h->ring_dom0[slot]));
+            NL_HIP(hipEventCreate(&h->ring_dom1[slot]));
+        }
         h->ev_start = h->ring_start[slot]; h->ev_stop = h->ring_stop[slot];
         h->ev_dom0 = h->ring_dom0[slot]; h->ev_dom1 = h->ring_dom1[slot];
     }
     const bool timed = !(h->dev_flags & 32u);         // developer switch 32: a pass without its timing events
+    h->ring_timed[h->pass_seq % kTimingRing] = timed;
     if (timed) NL_HIP(hipEventRecord(h->ev_start, h->stream));
     // The sigma / winsorized fast path from 17 frames on (a zonal kernel followed by a generic pass) runs the
     // FUSED protocol (StackArgs::final): no memset in front of the pass -- the previous fused pass's dominant
@@ -970,6 +1044,55 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         f.in_list = nullptr;
         f.in_count = nullptr;
         f.in_capacity = 0;
+        // winsorized clipping of 16 ... 128 frames: the winsorization cascade (stack_fast_sigma_impl.hpp) -- the dominant
+        // kernel and a second stage stop at a budget of rounds per wave and hand their unfinished pixels on, a third
+        // stage finishes them.  Lists and states live in the buffers of the linear-fit cascade (same sizes, never in
+        // use at the same time); their lengths in the scratch set.  NL_WCAS="b1,b2" sets the budgets, "0" turns it off;
+        // developer switch 128: off (A/B inside one process)
+        bool cascade = false;
+        if (mode == NL_ST_WINSOR_SIGMA && a.n_frames <= 128 && a.n_frames >= 16 && !(h->dev_flags & 128u)) {
+            // plan: "passes:cap[:group]" per stage, comma-separated, the dominant kernel first; the last stage runs to the end
+            struct Plan { int stages; int pass[nl::kCascadeStages], cap[nl::kCascadeStages], group[nl::kCascadeStages]; };
+            auto parse = [](const char *e, Plan *pl) {
+                pl->stages = 0;
+                const char *p = e;
+                while (*p && pl->stages < nl::kCascadeStages) {
+                    char *end = nullptr;
+                    const long a1 = strtol(p, &end, 10);
+                    if (end == p || *end != ':') break;
+                    p = end + 1;
+                    const long a2 = strtol(p, &end, 10);
+                    if (end == p) break;
+                    long a3 = 4;
+                    if (*end == ':') { p = end + 1; a3 = strtol(p, &end, 10); if (end == p) break; }
+                    pl->pass[pl->stages] = (int)a1;
+                    pl->cap[pl->stages] = (int)a2;
+                    pl->group[pl->stages] = a3 < 1 ? 1 : (a3 > 16 ? 16 : (int)a3);
+                    pl->stages++;
+                    if (*end != ',') break;
+                    p = end + 1;
+                }
+            };
+            static const Plan env_plan = [&] { Plan p0{}; const char *e = getenv("NL_WCAS"); if (e) parse(e, &p0); return p0; }();
+            static const bool env_off = [] { const char *e = getenv("NL_WCAS"); return e && e[0] == '0' && e[1] == 0; }();
+            Plan pl{};
+            if (env_plan.stages >= 2) pl = env_plan;
+            else if (a.n_frames <= kWinsorCascadeMaxFrames) parse(a.n_frames <= 40 ? kWinsorPlanShallow : kWinsorPlanDeep, &pl);
+            nl::LinfitCascade cb;
+            // (a list holds at most one entry per pixel of the tile, rounded up to whole workgroups: list and states of a
+            // stage share one of the cascade's state arrays, 4 words per pixel; the region lengths take its pixel lists)
+            if (!env_off && pl.stages >= 2 && h->npix >= 65536 && linfit_cascade(h, 1, &cb)) {
+                cascade = true;
+                for (int i = 0; i < 2; i++) {
+                    unsigned *base = reinterpret_cast<unsigned *>(cb.state[i]);
+                    f.cas_list[i] = base;
+                    f.cas_state[i] = base + 2 * (size_t)h->npix;
+                    f.cas_count[i] = cb.list[i];
+                }
+                f.cas_stages = pl.stages;
+                for (int k = 0; k < pl.stages; k++) { f.cas_pass[k] = pl.pass[k]; f.cas_cap[k] = pl.cap[k]; f.cas_group[k] = pl.group[k]; }
+            }
+        }
         // exact replay of the undecidable pixels: one wave per pixel where available.  The
         // hand-overs of the dominant kernel are replayed on a side stream WHILE the generic
         // pass runs (both only depend on the dominant kernel); what the generic pass adds
@@ -995,14 +1118,17 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
         static const bool coop4_env = [] { const char *e = getenv("NL_COOP4"); return e && e[0] == '1'; }();
         const bool coop4 = coop && coop4_env && nl::coop4_supported(mode, weighted, a.n_frames) != 0;
         if (coop4) { grid0 = (grid0 + 3) / 4; grid1 = (grid1 + 3) / 4; }
-        struct Fork { nl_stack *h; nl::StackArgs e; int mode; unsigned *snap; int grid0; bool coop4; hipError_t err; } fork{h, e, mode, snap, grid0, coop4, hipSuccess};
+        struct Fork { nl_stack *h; nl::StackArgs e; int mode; unsigned *snap; int grid0; bool coop4; bool cascade; hipError_t err; } fork{h, e, mode, snap, grid0, coop4, cascade, hipSuccess};
         nl::AfterDominant after = nullptr;
         if (coop) after = [](void *u) {
             Fork *k = static_cast<Fork *>(u);
             nl_stack *hh = k->h;
             const char *ignored = "";
-            hipEvent_t fork_ev = (hh->dev_flags & 32u) ? hh->ev_fork : hh->ev_dom1;      // (ev_dom1: recorded just now, behind the dominant kernel)
-            hipError_t err = (hh->dev_flags & 32u) ? hipEventRecord(hh->ev_fork, hh->stream) : hipSuccess;
+            // (ev_dom1: recorded behind the dominant kernel.  With a winsorization cascade two more kernels have filled the
+            // lists since: an event of its own)
+            const bool own = (hh->dev_flags & 32u) || k->cascade;
+            hipEvent_t fork_ev = own ? hh->ev_fork : hh->ev_dom1;
+            hipError_t err = own ? hipEventRecord(hh->ev_fork, hh->stream) : hipSuccess;
             if (hh->dev_flags & 2u) {            // developer switch: the first replay in front of the generic pass, same stream
                 nl::StackArgs first = k->e;
                 first.list_snap = k->snap;
@@ -1112,9 +1238,7 @@ int nl_stack_run_async(nl_stack_t *h, int mode, float sigma_low, float sigma_hig
             a.bounds = h->d_bounds;
             a.nrounds = h->d_nrounds;
             nl::FastArgs f;
-            f.fb_list = nullptr; f.fb_count = nullptr; f.fb_capacity = 0; f.fb_snap = nullptr;
-            f.gen_list = nullptr; f.gen_count = nullptr; f.gen_capacity = 0; f.gen_hint = 0;
-            f.in_list = nullptr; f.in_count = nullptr; f.in_capacity = 0;
+            memset(&f, 0, sizeof f);
             f.record_only = 1;
             const char *ignored = "";
             NL_HIP(nl::launch_stack_sigma_mlz(a, f, h->stream, &ignored, mode == NL_ST_WINSOR_SIGMA));
@@ -1258,6 +1382,8 @@ int nl_stack_pass_times(nl_stack_t *h, int back, float *pass_ms, float *dominant
     if (back < 0 || back >= kTimingRing || (int64_t)back >= h->pass_seq)
         return fail(NL_ERR_INVALID_ARG, "pass_times: pass %d back is not in the ring of %d", back, kTimingRing);
     const int slot = (int)((h->pass_seq - 1 - back) % kTimingRing);
+    if (!h->ring_timed[slot])
+        return fail(NL_ERR_INVALID_ARG, "pass_times: pass %d back ran without timing events (developer switch 32)", back);
     NL_HIP(hipEventSynchronize(h->ring_stop[slot]));
     float ms = -1.0f;
     if (pass_ms) {

@@ -188,7 +188,7 @@ int nl_group_run(nl_group_t *g, int mode, float sigma_low, float sigma_high, flo
     size_t started = 0;
     for (; started < g->tiles.size() && first_rc == NL_OK; started++)
         note(nl_stack_run_async(g->tiles[started], mode, sigma_low, sigma_high, ref_loc));
-    if (first_rc != NL_OK) started--;                     // the failing tile enqueued nothing to wait for
+    if (first_rc != NL_OK) started--;                     // (nl_stack_run_async settles a handle whose pass failed: nothing of it is in flight)
     int64_t lo = 0, hi = 0;
     for (size_t t = 0; t < started; t++) {
         int64_t l = 0, h = 0;

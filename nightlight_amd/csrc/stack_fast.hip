@@ -488,7 +488,7 @@ static const char *sigma_kernel_name()
 {
     static const std::string name = std::string("stack_sigma_fast_kernel<") + std::to_string(NS) + ", " +
                                     (ZONAL ? "true" : "false") + ", " + (WINSOR ? "true" : "false") + ", " +
-                                    (TIGHT ? "true" : "false") + ", false>";
+                                    (TIGHT ? "true" : "false") + ", false, false>";
     return name.c_str();
 }
 
@@ -508,6 +508,17 @@ static hipError_t launch_pair(const StackArgs &args, const FastArgs &fargs, unsi
     f.in_count = nullptr;
     f.in_capacity = 0;
     if constexpr (NS >= kZonalMinSize) {
+        f.cont_list = nullptr; f.cont_state = nullptr; f.cont_count = nullptr; f.cont_region = 0; f.in_state = nullptr;
+        f.in_region = f.in_regions = f.in_group = 0;
+        f.pass_budget = f.round_cap = 0;
+        if (WINSOR && fargs.cas_list[0]) {            // first stage of the winsorization cascade: one region per workgroup
+            f.cont_list = fargs.cas_list[0];
+            f.cont_state = fargs.cas_state[0];
+            f.cont_count = fargs.cas_count[0];
+            f.cont_region = 256;
+            f.pass_budget = fargs.cas_pass[0];
+            f.round_cap = fargs.cas_cap[0];
+        }
         if (args.n_frames == NS) {
             *name = sigma_kernel_name<NS, true, WINSOR, true>();
             hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true, WINSOR, true>), dim3(tile_blocks), dim3(256), 0,
@@ -519,6 +530,39 @@ static hipError_t launch_pair(const StackArgs &args, const FastArgs &fargs, unsi
         }
         keep_first(err, hipGetLastError());
         if (dominant_done) keep_first(err, hipEventRecord(dominant_done, stream));
+        if constexpr (WINSOR) {
+            // winsorization cascade (stack_fast_sigma_impl.hpp): the dominant kernel above stopped at its budget; two more
+            // stages over the continuation lists, in freshly packed waves, the last one without a budget
+            if (fargs.cas_list[0]) {
+                FastArgs g = f;
+                unsigned regions = tile_blocks, region = 256;          // of the list the stage reads
+                for (int st = 1; st < fargs.cas_stages; st++) {
+                    const bool last = st == fargs.cas_stages - 1;
+                    const unsigned group = (unsigned)fargs.cas_group[st];
+                    const unsigned blocks = (regions + group - 1) / group;
+                    g.in_list = fargs.cas_list[(st - 1) & 1];
+                    g.in_state = fargs.cas_state[(st - 1) & 1];
+                    g.in_count = fargs.cas_count[(st - 1) & 1];
+                    g.in_capacity = 0;
+                    g.in_region = region;
+                    g.in_regions = regions;
+                    g.in_group = group;
+                    g.cont_list = last ? nullptr : fargs.cas_list[st & 1];
+                    g.cont_state = last ? nullptr : fargs.cas_state[st & 1];
+                    g.cont_count = last ? nullptr : fargs.cas_count[st & 1];
+                    g.cont_region = region * group;                   // (a workgroup cannot hand on more than it was given)
+                    g.pass_budget = last ? 0 : fargs.cas_pass[st];
+                    g.round_cap = last ? 0 : fargs.cas_cap[st];
+                    if (args.n_frames == NS)
+                        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true, WINSOR, true, false, true>), dim3(blocks), dim3(256), 0, stream, args, g);
+                    else
+                        hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true, WINSOR, false, false, true>), dim3(blocks), dim3(256), 0, stream, args, g);
+                    keep_first(err, hipGetLastError());
+                    regions = blocks;
+                    region = region * group;
+                }
+            }
+        }
         if (after) after(user);
         // generic pass over the pixels the zonal waves handed over (its length
         // is only known on the device: fixed grid, grid-stride loop); chunked passes run it on

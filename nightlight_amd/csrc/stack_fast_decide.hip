@@ -28,8 +28,8 @@ template <int NS, bool WINSOR>
 static void launch_decide(const StackArgs &args, unsigned blocks, hipStream_t stream, const char **name)
 {
     static const std::string names[2] = {
-        std::string("stack_sigma_fast_kernel<") + std::to_string(NS) + ", true, " + (WINSOR ? "true" : "false") + ", false, true>",
-        std::string("stack_sigma_fast_kernel<") + std::to_string(NS) + ", true, " + (WINSOR ? "true" : "false") + ", true, true>"};
+        std::string("stack_sigma_fast_kernel<") + std::to_string(NS) + ", true, " + (WINSOR ? "true" : "false") + ", false, true, false>",
+        std::string("stack_sigma_fast_kernel<") + std::to_string(NS) + ", true, " + (WINSOR ? "true" : "false") + ", true, true, false>"};
     FastArgs f;
     memset(&f, 0, sizeof f);
     if (args.n_frames == NS) {

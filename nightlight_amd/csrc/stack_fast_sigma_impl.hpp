@@ -22,13 +22,27 @@ namespace nl {
 //                (undecidable sample, zone overflow, too many missing samples or rounds).  The bit-exact replay then
 //                only permutes and clips (no sums, no winsorization) and forms the weighted mean.  Writes no result,
 //                no counters and no lists.
+// The winsorization CASCADE (winsorized zonal kernels; FastArgs::pass_budget, round_cap, cont_*).  A wave runs its
+// winsorization loop (stack.go:649-672 as an interval, WinsorInterval) until its slowest lane is through, in every
+// clipping pass, and clipping passes until its slowest lane needs no more: measured on the bench stack
+// (tools/round_stats.py) a wave executes 44 rounds in 3.3 passes at 16 frames, 28 in 3.4 at 128, where a lane needs 7 ... 10
+// rounds in 1.3 ... 1.8 passes -- the kernel's time is those rounds.  A stage of the cascade runs at most pass_budget
+// clipping passes per wave with at most round_cap winsorization rounds each: lanes still inside a winsorization loop at
+// the cap fall back to the state they entered that pass with, and whoever is not done at the end is appended -- pixel,
+// clip counts so far -- to the continuation list.  The next stage (CONT: zonal kernel over that list) gathers and sorts
+// those pixels again (deterministic: the counts address the same samples), in freshly packed waves, and carries on.
+// Only the stage that finishes a pixel books its counters, so a pixel that turns undecidable in a later stage is
+// replayed from scratch as before.
+// CONT (zonal only): the kernel runs over q.in_list / q.in_state instead of the tile.
 
-template <int NS, bool ZONAL, bool WINSOR, bool TIGHT, bool RECORD = false>
+template <int NS, bool ZONAL, bool WINSOR, bool TIGHT, bool RECORD = false, bool CONT = false>
 __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
 {
     static_assert(!TIGHT || ZONAL, "TIGHT is a variant of the zonal kernels");
     static_assert(!RECORD || ZONAL, "RECORD is a variant of the zonal kernels");
-    if constexpr (ZONAL && !RECORD) fused_prologue_dominant(p);
+    static_assert(!CONT || (ZONAL && WINSOR && !RECORD), "CONT continues a winsorized zonal pass");
+    constexpr bool CASCADE = ZONAL && WINSOR && !RECORD;      // this instantiation knows about budgets and continuation lists
+    if constexpr (ZONAL && !RECORD && !CONT) fused_prologue_dominant(p);
     if constexpr (!ZONAL) { if (q.in_list) { fused_collect_slots(p); snapshot_fb_list(q); } }
     // zone widths: 8 clipped + 8 missing samples per lane for the larger
     // networks, 4 + 4 for the small ones
@@ -41,12 +55,37 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
     // ZONAL, or GENERIC without a list: the grid covers the tile, one pixel per
     // lane, a single trip.  GENERIC with a list: grid-stride over the hand-over
     // list, whose length is only known on the device.
-    const bool listed = !ZONAL && q.in_list != nullptr;
-    const int64_t limit = listed ? (int64_t)min(*q.in_count, q.in_capacity) : p.npix;
-    const int64_t sweep = listed ? (int64_t)gridDim.x * blockDim.x : limit;
+    const bool listed = (!ZONAL || CONT) && q.in_list != nullptr;
+    int64_t limit = listed ? (int64_t)min(*q.in_count, q.in_capacity) : p.npix;
+    int64_t sweep = listed ? (int64_t)gridDim.x * blockDim.x : limit;
+    int64_t wg_first = (int64_t)blockIdx.x * blockDim.x;
+    // CASCADE: this workgroup's continuation region fills through an LDS counter (no device atomics, see FastArgs)
+    __shared__ unsigned s_cont, s_pref[17];
+    if constexpr (CASCADE) {
+        if (threadIdx.x == 0) s_cont = 0u;
+    }
+    if constexpr (CONT) {
+        // input: q.in_group consecutive regions of the previous stage's list, first region blockIdx.x * in_group; the
+        // items of the group are numbered through (prefix sums of the regions' lengths in s_pref), 256 per trip
+        if (threadIdx.x == 0) {
+            unsigned acc = 0;
+            for (unsigned r = 0; r < q.in_group; r++) {
+                const unsigned reg = blockIdx.x * q.in_group + r;
+                s_pref[r] = acc;
+                acc += reg < q.in_regions ? min(q.in_count[reg], q.in_region) : 0u;
+            }
+            s_pref[q.in_group] = acc;
+        }
+        __syncthreads();
+        limit = (int64_t)s_pref[q.in_group];
+        wg_first = 0;
+        sweep = blockDim.x;
+    } else if constexpr (CASCADE) {
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
 
-    for (int64_t wg_item = (int64_t)blockIdx.x * blockDim.x; wg_item < limit; wg_item += sweep) {
+    for (int64_t wg_item = wg_first; wg_item < limit; wg_item += sweep) {
         // the frame count is re-read through an opaque register every trip:
         // otherwise the compiler hoists the 128 per-frame scalar selects that
         // depend on it out of the loop and spills them
@@ -55,7 +94,13 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         const int64_t item = wg_item + threadIdx.x;
         const bool on = item < limit;
         int64_t pix = item;
-        if (listed) pix = on ? (int64_t)q.in_list[item] : 0;
+        unsigned cas_at = 0;                                 // CONT: where this lane's item sits in the previous stage's list
+        if constexpr (CONT) {
+            unsigned r = 0;
+            for (unsigned k = 1; k < q.in_group; k++) r += ((unsigned)item >= s_pref[k]) ? 1u : 0u;      // (regions may be empty: count them all)
+            cas_at = (blockIdx.x * q.in_group + r) * q.in_region + ((unsigned)item - s_pref[r]);
+            pix = on ? (int64_t)q.in_list[cas_at] : 0;
+        } else if (listed) pix = on ? (int64_t)q.in_list[item] : 0;
         const unsigned boff = (unsigned)(on ? pix : 0) * 4u;     // byte offset inside a frame
 
         // A genuine +-Inf sample stays among the n valid ones, makes the variance
@@ -137,6 +182,19 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
             q_in = (q0 + q1) + (q2 + q3);
         }
 
+        if constexpr (CONT) {
+            // the clip counts an earlier stage left: the survivors are sorted positions [a + c_lo, b - c_hi) (the shift c
+            // and the fixed sums above are those of the first stage: same arithmetic, same result bits)
+            const unsigned st = on ? q.in_state[cas_at] : 0u;
+            c_lo = (int)(st & 0xffffu);
+            c_hi = (int)(st >> 16);
+            a += c_lo;
+            b -= c_hi;
+        }
+        // clipping passes this wave may still run in this stage (wave-uniform)
+        int passes_left = (CASCADE && q.pass_budget > 0) ? q.pass_budget : 0x7fffffff;
+        bool defer = false;                    // CASCADE: not done within the stage's budget -> continuation list
+
         // max|x| over the survivors (only enters the reference-mean error term):
         // first pass from the two ends of the sorted column, afterwards from the
         // bounds every survivor passed
@@ -145,6 +203,14 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         int rnd = 0;                           // RECORD: clipping rounds decided so far
         if (ZONAL && lane == 0) NL_STAT(4, 1);
         while (__any(active)) {
+            if constexpr (CASCADE) {
+                if (passes_left <= 0) {                    // whoever needs another pass takes it in the next stage
+                    defer = defer || active;
+                    active = false;
+                    break;
+                }
+                passes_left--;
+            }
             if (ZONAL) { if (lane == 0) NL_STAT(2, 1); if (active) NL_STAT(3, 1); }
             // re-materialised per pass: otherwise the differences v[k] - c of every masked
             // position are hoisted out of the loop (one register each -- 128 in the generic pass;
@@ -227,7 +293,16 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                 wi.start(s_min, s_max);
                 const float inv_cnt = 1.0f / fcnt;
                 bool inner = active && !bail;
+                int rounds_left = (CASCADE && q.round_cap > 0) ? q.round_cap : 0x7fffffff;
                 while (__any(inner)) {
+                    if constexpr (CASCADE) {
+                        if (rounds_left <= 0) {            // at the cap: these lanes re-enter this pass in the next stage
+                            defer = defer || inner;
+                            active = active && !inner;
+                            break;
+                        }
+                        rounds_left--;
+                    }
                     if (ZONAL) { if (lane == 0) NL_STAT(0, 1); if (inner) NL_STAT(1, 1); }
                     wi.next_clamp(median, xmin, xmax);
                     // variance of clamp(x, Lt, Ht) over the survivors (shifted moments) and its error bound
@@ -440,10 +515,24 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
             const bool decided = on && !to_generic && !to_exact && n > 0 && rnd <= kBoundRounds;
             if (on) p.nrounds[pix] = (unsigned char)(decided ? rnd : 0);
         } else {
-        if (on && !to_generic && !to_exact) {
+        if (on && !to_generic && !to_exact && !defer) {
             p.out[pix] = res;
             c_lo_total += c_lo;
             c_hi_total += c_hi;
+        }
+        if constexpr (CASCADE) {
+            const unsigned long long dm = __ballot(on && defer);
+            if (dm) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&s_cont, (unsigned)__popcll(dm));       // LDS
+                base = __shfl(base, 0, 64);
+                const unsigned slot = base + (unsigned)__popcll(dm & ((1ull << lane) - 1ull));
+                if (on && defer && slot < q.cont_region) {
+                    const size_t at = (size_t)blockIdx.x * q.cont_region + slot;
+                    q.cont_list[at] = (unsigned)pix;
+                    q.cont_state[at] = (unsigned)c_lo | ((unsigned)c_hi << 16);
+                }
+            }
         }
         // hand-over lists: one atomic per wave reserves a contiguous run, lanes
         // fill it in lane order, so the consumer's loads stay coalesced
@@ -468,6 +557,12 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         }
     }
     if constexpr (RECORD) return;
+    if constexpr (CASCADE) {
+        if (q.cont_count) {                                    // this workgroup's region length (every workgroup stores one: no zeroing)
+            __syncthreads();
+            if (threadIdx.x == 0) q.cont_count[blockIdx.x] = min(s_cont, q.cont_region);
+        }
+    }
 
     // clip totals: wave sum -> block sum -> one slot per workgroup
     __shared__ int s_lo[4], s_hi[4];

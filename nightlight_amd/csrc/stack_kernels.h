@@ -69,6 +69,29 @@ struct FastArgs {
     const unsigned *in_list;      // generic pass: list to process (nullptr = the whole tile)
     const unsigned *in_count;
     unsigned in_capacity;
+    // Winsorization cascade of the one-lane winsorized kernels (stack_fast_sigma_impl.hpp).  Host-side plan, filled in by
+    // nlstack_api.hip: two continuation lists (pixel, clip counts so far) with their per-workgroup lengths and the wave
+    // budgets of the first two stages (winsorization rounds; the third stage runs to the end).  cas_list[0] == nullptr:
+    // no cascade.  NO global atomics: a workgroup of a stage compacts its unfinished pixels into a region of its own
+    // (through an LDS counter) and stores the region's length; a workgroup of the next stage takes cas_group consecutive
+    // regions.  (One device counter for the 262 144 waves of a 4096^2 tile costs 3 ms -- 11 ns per atomic, all in one L2
+    // channel -- whether it is one word or 256 neighbouring ones: measured, the dominant kernel got slower with a budget.)
+    // Stage k (0 = the dominant kernel) appends to list k % 2 and, from k = 1 on, reads list (k - 1) % 2; it may run
+    // cas_pass[k] clipping passes per wave with at most cas_cap[k] winsorization rounds each (0 = no limit: the last stage).
+    unsigned *cas_list[2];
+    unsigned *cas_state[2];
+    unsigned *cas_count[2];       // lengths of the regions of the two lists (one region per workgroup of the stage that filled it)
+    int cas_stages;               // stages in all, 2 ... kCascadeStages
+    int cas_pass[6], cas_cap[6];
+    int cas_group[6];             // [k]: regions of its input list per workgroup of stage k (k >= 1), at most 16
+    // ... and what one launch of the cascade works with (set by the launcher from the plan above)
+    unsigned *cont_list;          // where this stage appends its unfinished pixels: region blockIdx.x, cont_region entries long
+    unsigned *cont_state;
+    unsigned *cont_count;         // [workgroups of this launch]
+    unsigned cont_region;
+    const unsigned *in_state;     // CONT kernels: the states that belong to in_list; in_count = the regions' lengths
+    unsigned in_region, in_regions, in_group;      // entries per input region, number of regions, regions per workgroup
+    int pass_budget, round_cap;   // clipping passes a wave may run in this stage / winsorization rounds per pass (0 = no limit)
     int record_only = 0;          // LDS-column kernels as the DECISION pass of a weighted stack (129 ... 512 frames): no outputs, no
                                   // lists, no counters -- only StackArgs::bounds / nrounds (0 rounds for a pixel they would hand over)
 };
@@ -198,10 +221,12 @@ hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs,
                                    const char **name, hipEvent_t dominant_done,
                                    bool winsor, AfterDominant after_dominant, void *user, hipStream_t tail = nullptr);
 
+constexpr int kCascadeStages = 6;   // most stages of a winsorization cascade, the dominant kernel included
 // rounds of clip bounds a decision pass records per pixel (pixels that need more are replayed in full)
 constexpr int kBoundRounds = 8;
 // ---- stack_fast_decide.hip: the register-resident kernels as the DECISION pass of weighted sigma / winsorized
-// stacks (StackArgs::bounds / nrounds); 45..128 frames ----
+// stacks (StackArgs::bounds / nrounds); 33 ... 128 frames (decide_supported); 129 ... 512 frames: the LDS-column kernel
+// of the frame-count class, record-only (decide_ml_supported) ----
 int decide_supported(int mode, int n_frames, int64_t npix);
 int decide_ml_supported(int mode, int n_frames, int64_t npix);      // 129 ... 512 frames: the LDS-column kernel of the class, FastArgs::record_only
 hipError_t launch_stack_sigma_decide(const StackArgs &args, hipStream_t stream, bool winsor, const char **name);
@@ -239,8 +264,9 @@ constexpr int kTileMaxFramesSigma = 40, kTileMaxFramesWinsor = 32;
 // vs 26.0; winsorized 36 frames 27.2 (tile) vs 16.6, 44: 36.2 vs 17.4, 96: 35.5 (four) vs 28.9, 128: 52.6 vs 38.3;
 // with four pixels per work item (stack_exact_coop.hip, GROUP): sigma 34 frames 8.5 (tile) vs 11.1, 40: 11.4 vs 11.7,
 // 44: 13.7 vs 12.0.)  Four pixels per wave stays for winsorized stacks WITHOUT a decision pass (since the LDS-column
-// kernels decide 129 ... 512 frames: developer switch 4 or no memory for the bounds), 129 ...
-// kCoop4MaxFrames (ms per 2048 x 4096 pixels: 136 frames 65 vs 89, 160: 79 vs 93, 192: 115 vs 98).
+// kernels decide 129 ... 512 frames: only with developer switch 4 or without memory for the bounds), for
+// kCoop4MinFrames ... kCoop4MaxFrames frames (ms per 2048 x 4096 pixels, four pixels per wave vs one: 136 frames 65 vs 89,
+// 160 frames 79 vs 93, 192 frames 115 vs 98).
 constexpr int kCoop4MinFrames = 129, kCoop4MaxFrames = 176;
 int tile_supported(int mode, bool weighted, int n_frames);
 hipError_t launch_stack_sigma_tile(int mode, const StackArgs &args, int grid, hipStream_t stream, const char **name);

@@ -381,13 +381,17 @@ bool OpStackBatches::partition(const std::vector<Promise> &ins, Context *c, std:
     snprintf(line, sizeof line, "\nEstimating memory needs for %lld images from %s:\n", (long long)numFrames,
              first.image->FileName.c_str());
     if (c->Log) *c->Log << line;
-    if (first.image->Naxisn.size() < 2 || first.image->Naxisn[0] <= 0 || first.image->Naxisn[1] <= 0 ||
-        (int64_t)first.image->Naxisn[0] * first.image->Naxisn[1] != (int64_t)first.image->Data.size()) {
-        *err = "No input files to prepare batches";          // a frame without a 2-D shape cannot size the batches
+    // the reference's estimate reads Naxisn[0] and Naxisn[1] only (stackbatches.go:130-141); its stack is generic
+    // over len(Data)
+    if (first.image->Naxisn.size() < 2 || first.image->Naxisn[0] <= 0 || first.image->Naxisn[1] <= 0) {
+        *err = "First image has no two-dimensional shape to estimate memory needs from";
         return false;
     }
     const int64_t width = first.image->Naxisn[0], height = first.image->Naxisn[1];
-    FirstWidth = (int)width; FirstHeight = (int)height;
+    // what sizes a RESIDENT device group (more than one batch, Apply below): every sample of a frame as rows of
+    // `width` -- a cube (NAXIS = 3) becomes a taller image, as the reference's flat Data is
+    FirstWidth = (int)width;
+    FirstHeight = (int64_t)first.image->Data.size() % width == 0 ? (int)((int64_t)first.image->Data.size() / width) : 0;
     const int64_t pixels = width * height;
     const float mPixels = (float)width * (float)height * 1e-6f;
     const int64_t bytes = pixels * 4;
@@ -469,6 +473,7 @@ Result OpStackBatches::Apply(const std::vector<Promise> &ins, Context *c)
     if (numBatches > 1 && PerBatch) {
         // sized by the frame partition() already loaded (the promise is not run a second time)
         const std::vector<int> devs = devices_for(c);
+        if (FirstHeight <= 0) return {nullptr, "Frame data is not a whole number of image rows: cannot size the device buffers"};
         resident = nl_group_create((int)batchSize, FirstWidth, FirstHeight, (int)devs.size(), devs.data());
         if (!resident) return {nullptr, nl_last_error()};
         PerBatch->Resident = resident;

@@ -98,6 +98,11 @@ class StackHandle:
     def fill_synthetic(self, seed=0x4E4C5354):
         capi.check(self._lib.nl_stack_fill_synthetic(self._h, C.c_uint64(seed)))
 
+    @property
+    def device_bytes(self):
+        """Device memory the handle holds right now (create-time buffers + lazily allocated scratch)."""
+        return int(self._lib.nl_stack_device_bytes(self._h))
+
     def frames_device_ptr(self):
         return self._lib.nl_stack_frames_device_ptr(self._h)
 

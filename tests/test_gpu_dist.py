@@ -174,3 +174,104 @@ def test_eight_ranks_tile_the_headline_stack_on_one_device():
     assert doc["config"]["frames"] == 128 and doc["config"]["image_rows"] == 4096 and doc["config"]["rows_per_gpu"] == 512
     assert (doc["config"]["clip_low"], doc["config"]["clip_high"]) == (6836157, 13270993)
     assert doc["roofline"]["algorithmic_bytes"] == 4.0 * 512 * 4096 * 129
+
+
+# ---- RCCL itself, on the one GPU there is: a process group of world size 1 with backend "nccl" ----------------------
+# (internal/ops/stack/stack.go:193-198: the clip totals every pass, and every goal-seek step, reduces.)  The scaling run
+# is the driver's; what can be executed here is every line of it except the second rank: communicator set-up, the
+# device-to-device copy of the counters behind a pass, an asynchronous all-reduce on the handle's own stream
+# (ExternalStream), and the goal-seek's reduction callback backed by the same collective.
+
+def _rccl_worker(_index, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import nightlight_amd as nl
+    from nightlight_amd.dist import ShardedStack
+    from util import make_frames as mk
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    frames = mk(N, W, H, seed=7300)
+
+    def make_tile(row0, rows):
+        st = nl.StackHandle(N, W, H, row0=row0, rows=rows, device=0)
+        st.upload_frames(frames)
+        return st
+
+    sh = ShardedStack(H, make_tile, world=1, rank=0, device="cuda")       # counters all-reduced as a CUDA tensor: RCCL
+    out = {}
+    for mode in (2, 3, 5):
+        res, cl, ch = sh.run(mode, 2.5, 2.5)
+        out["res%d" % mode] = res
+        out["clip%d" % mode] = np.array([cl, ch])
+    gs = sh.find_sigmas(2, 1.0, 1.0)                                      # nl_reduce_fn -> dist.all_reduce on the device
+    # the bench's per-pass protocol: counters copied device-to-device behind the pass, reduced asynchronously on the
+    # handle's own stream, the next pass enqueued meanwhile
+    st = sh.tile
+    totals = torch.zeros(2, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.ExternalStream(st.stream_ptr, device=0)
+    pending = None
+    seen = []
+    for it in range(4):
+        st.run_async(2, 2.5 + 0.25 * it, 2.5)
+        with torch.cuda.stream(stream):
+            if pending is not None:
+                pending.wait()
+                seen.append(totals.clone())
+            st.copy_counters_async(totals.data_ptr())
+            pending = dist.all_reduce(totals, async_op=True)
+    with torch.cuda.stream(stream):
+        pending.wait()
+    st.finish()
+    torch.cuda.synchronize()
+    seen.append(totals.clone())
+    np.savez(out_path, gs_res=gs[0], gs=np.array(gs[1:], np.float64), backend=np.array([dist.get_backend()]),
+             async_totals=np.stack([t.cpu().numpy() for t in seen]), **out)
+    sh.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_world_size_one_runs_the_device_side_reduction(tmp_path, oracle, nl):
+    import torch.multiprocessing as mp
+    port = 31600 + (os.getpid() % 2000)
+    out_path = os.path.join(str(tmp_path), "rccl.npz")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    mp.spawn(_rccl_worker, args=(port, out_path), nprocs=1, join=True)
+    d = np.load(out_path)
+    assert str(d["backend"][0]) == "nccl"
+    frames = make_frames(N, W, H, seed=7300)
+    for mode in (2, 3, 5):
+        rc, want, wl, wh, _ = oracle.stack_apply(mode, frames, None, 2.5, 2.5)
+        assert tuple(d["clip%d" % mode]) == (wl, wh)
+        got = d["res%d" % mode]
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        ok = ~np.isnan(want)
+        assert np.all(np.abs(got[ok].astype(np.float64) - want[ok]) <= 1e-5 * np.abs(want[ok]))
+    passes, gres, gcl, gch, gsl, gsh = oracle.find_sigmas_bisect(2, frames, 1.0, 1.0)
+    assert tuple(d["gs"][:2]) == (gcl, gch) and int(d["gs"][4]) == passes
+    assert (np.float32(d["gs"][2]), np.float32(d["gs"][3])) == (gsl, gsh)
+    # the asynchronous per-pass totals: pass i's counters, reduced while pass i+1 ran
+    for it in range(4):
+        rc, _, wl, wh, _ = oracle.stack_apply(2, frames, None, 2.5 + 0.25 * it, 2.5)
+        assert tuple(int(x) for x in d["async_totals"][it]) == (wl, wh), it
+
+
+def test_bench_force_dist_reports_the_rccl_protocol_on_one_gpu():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "16", "--width", "256", "--height", "96",
+            "--steps", "3", "--warmup", "1", "--no-cpu"]
+    p = subprocess.run(base + ["--force-dist"], env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    doc = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert doc["n_gpus"] == 1
+    assert "on the device (RCCL, the pass's own stream)" in doc["config"]["sharding"]
+    p1 = subprocess.run(base, env=env, capture_output=True, text=True, timeout=280)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    one = json.loads([ln for ln in p1.stdout.splitlines() if ln.startswith("{")][0])
+    assert "RCCL" not in one["config"]["sharding"]
+    assert (one["config"]["clip_low"], one["config"]["clip_high"]) == (doc["config"]["clip_low"], doc["config"]["clip_high"])
+    assert "fresh_handle" in one and one["fresh_handle"]["ms_first_pass_fresh_handle"] > 0
+    assert one["fresh_handle"]["clip_counters"] == [one["config"]["clip_low"], one["config"]["clip_high"]]

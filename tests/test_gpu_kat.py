@@ -47,6 +47,8 @@ def test_known_answers_on_the_gpu(nl, case, exact):
         assert np.all(got == want), (kernel, got[:3], want)
         for what, wrong in case.get("wrong_answers", {}).items():
             assert not np.any(got == np.float32(wrong)), what
+    for what, wrong in case.get("wrong_counters", {}).items():
+        assert [cl, ch] != [WIDTH * c for c in wrong], what
 
 
 def test_committed_fixture_on_the_gpu(nl):

@@ -98,7 +98,7 @@ def test_tight_zonal_variant_exact_sizes(nl, oracle, mode, n, nan_frac):
         st.set_exact(False)
         got, cl, ch = st.run(mode, 2.5, 2.0, 0.0)
         name = st.last_kernel_name
-    assert name == "stack_sigma_fast_kernel<%d, true, %s, true, false>" % (n, "true" if mode == 3 else "false"), name
+    assert name == "stack_sigma_fast_kernel<%d, true, %s, true, false, false>" % (n, "true" if mode == 3 else "false"), name
     rc, want, wl, wh, _ = oracle.stack_apply(mode, frames, None, 2.5, 2.0, 0.0, num_cpu=4)
     assert rc == 0
     assert (cl, ch) == (wl, wh), "n=%d mode=%d clip counters %r vs oracle %r" % (n, mode, (cl, ch), (wl, wh))
@@ -759,3 +759,18 @@ def test_developer_switches_do_not_change_results(nl, oracle, mode, n, weighted)
                 ref = (got.copy(), cl, ch)
             assert (cl, ch) == ref[1:], (flags, cl, ch, ref[1:])
             assert np.array_equal(got.view(np.uint32), ref[0].view(np.uint32)), flags
+
+
+def test_device_bytes_reports_the_lazily_allocated_scratch(nl):
+    # nl_stack_device_bytes: create-time buffers, then the decision-pass thresholds a weighted clip mode allocates
+    # on its first pass (65 bytes per pixel) and keeps until destroy
+    n, w, h = 64, 64, 32                # (weighted sigma clipping: decision pass from 41 frames on)
+    with nl.StackHandle(n, w, h) as st:
+        b0 = st.device_bytes
+        assert b0 >= n * w * h * 4 + w * h * 4
+        st.fill_synthetic(seed=3)
+        st.run(1)
+        assert st.device_bytes == b0                       # a mean pass allocates nothing
+        st.set_weights(np.linspace(0.2, 1.0, n).astype(np.float32))
+        st.run(2, 3.0, 3.0)
+        assert st.device_bytes >= b0 + 65 * w * h

@@ -24,6 +24,10 @@ def test_known_answers_c_oracle(oracle, case):
     assert rc == 0
     assert res[0] == np.float32(case["result"])
     assert [cl, ch] == case["clip"]
+    for what, wrong in case.get("wrong_answers", {}).items():          # (the mis-readings on record give other values)
+        assert np.float32(wrong) != np.float32(case["result"]), what
+    for what, wrong in case.get("wrong_counters", {}).items():
+        assert wrong != case["clip"], what
 
 
 @pytest.mark.parametrize("case", KAT["cases"], ids=[c["name"][:40] for c in KAT["cases"]])

@@ -85,6 +85,10 @@ func (op *OpStack) Apply(f []*fits.Image, c *ops.Context) (result *fits.Image, e
 		}
 		devs = &cdev[0]
 	}
+	// One group per Apply, as the reference allocates per call (stack.go:131-138).  nl_group_destroy parks the large
+	// device buffers, the next Apply with the same geometry takes them over (bench.py "fresh_handle": create + destroy
+	// 3 ms for the first handle of a process, well below one pass afterwards); C.nl_release_cached_memory() returns
+	// them to the driver when the process is done stacking.
 	g := C.nl_group_create(C.int(len(f)), C.int(width), C.int(height), C.int(len(Devices)), devs)
 	if g == nil {
 		return nil, lastError()

@@ -66,6 +66,12 @@ const char *nl_last_error(void);
 int nl_device_count(void);
 /* library version string */
 const char *nl_version(void);
+/* nl_stack_destroy parks the large device buffers of a handle (frames, result, hand-over lists; at most 16 blocks and
+ * NL_MEM_CACHE_MB MiB in all -- default 16 384, 0 turns the cache off) for the next nl_stack_create / nl_group_create of the
+ * same geometry on the same device: a drop-in that creates one handle per OpStack.Apply (stack.go:131-138 allocates per
+ * call, too) otherwise pays more for hipMalloc + hipFree than for the stack pass.  This returns the parked buffers to
+ * HIP (also done automatically when an allocation fails).  No counterpart in the reference. */
+void nl_release_cached_memory(void);
 
 /* ---- handle: replaces the per-call state of OpStack.Apply (stack.go:115-227) ---- */
 

@@ -31,7 +31,7 @@ ERR_NO_DEVICE = -9
 EXPORTS = [
     "nl_last_error", "nl_device_count", "nl_version",
     "nl_stack_create", "nl_stack_destroy",
-    "nl_stack_upload_frame", "nl_stack_upload_tile", "nl_stack_upload_frame_async", "nl_stack_upload_wait", "nl_stack_frames_device_ptr", "nl_stack_device_bytes",
+    "nl_stack_upload_frame", "nl_stack_upload_tile", "nl_stack_upload_frame_async", "nl_stack_upload_wait", "nl_stack_frames_device_ptr", "nl_stack_device_bytes", "nl_release_cached_memory",
     "nl_stack_attach_device_frames", "nl_stack_fill_synthetic", "nl_stack_download_tile", "nl_stack_download_rows",
     "nl_stack_set_active_frames", "nl_stack_set_weights", "nl_weights_from_scalars",
     "nl_stack_linfit_stage_counts", "nl_stack_run", "nl_stack_run_async", "nl_stack_finish", "nl_stack_result_device_ptr",

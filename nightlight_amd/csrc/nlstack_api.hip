@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -64,6 +65,79 @@ constexpr int kWinsorCascadeMaxFrames = 96;
 // per-pass device scratch, zeroed by one memset (or, in the fused protocol of the sigma / winsorized fast path, by
 // the previous pass's dominant kernel -- two sets alternate): clip accumulators + list lengths + snapshot
 constexpr size_t kScratchBytes = sizeof(unsigned long long) * nl::kScratchWords;
+
+// ---- device-memory cache ---------------------------------------------------------------------------------------------
+// The cgo drop-in creates a handle per OpStack.Apply (stack.go:131-138 allocates per call as well) and destroys it
+// afterwards: hipMalloc + hipFree of the frame buffer alone cost more than the headline pass (measured, bench.py
+// "fresh_handle": create 1.0 - 1.6 ms, destroy 1.3 - 1.8 ms, pass 1.7 ms).  The large buffers of a destroyed handle are
+// therefore parked -- at most kCacheBlocks of them, NL_MEM_CACHE_MB MiB in all (default 16 384; 0 = off) -- and the
+// next handle with the same sizes on the same device takes them over.  nl_release_cached_memory() returns them to HIP.
+constexpr int kCacheBlocks = 16;
+constexpr size_t kCacheMinBytes = (size_t)1 << 20;
+struct CachedBlock { int device; size_t bytes; void *ptr; };
+std::mutex g_cache_mu;
+std::vector<CachedBlock> g_cache;
+size_t g_cache_bytes = 0;
+
+size_t cache_limit()
+{
+    static const size_t lim = [] {
+        const char *e = getenv("NL_MEM_CACHE_MB");
+        const long long mb = e ? atoll(e) : 16384;
+        return mb > 0 ? (size_t)mb << 20 : (size_t)0;
+    }();
+    return lim;
+}
+
+void cache_release_all()
+{
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (const CachedBlock &b : g_cache) {
+        (void)hipSetDevice(b.device);
+        (void)hipFree(b.ptr);
+    }
+    g_cache.clear();
+    g_cache_bytes = 0;
+    (void)hipSetDevice(cur);
+}
+
+// (the caller has selected `device`)
+hipError_t cached_malloc(void **p, size_t bytes, int device)
+{
+    if (bytes >= kCacheMinBytes) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (size_t i = 0; i < g_cache.size(); i++)
+            if (g_cache[i].device == device && g_cache[i].bytes == bytes) {
+                *p = g_cache[i].ptr;
+                g_cache_bytes -= bytes;
+                g_cache.erase(g_cache.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && !g_cache.empty()) {             // out of memory with blocks parked: give them back and retry
+        (void)hipGetLastError();
+        cache_release_all();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+
+void cached_free(void *p, size_t bytes, int device)
+{
+    if (!p) return;
+    if (bytes >= kCacheMinBytes) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        if ((int)g_cache.size() < kCacheBlocks && g_cache_bytes + bytes <= cache_limit()) {
+            g_cache.push_back({device, bytes, p});
+            g_cache_bytes += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
 
 int next_pow2(int n)
 {
@@ -176,6 +250,8 @@ const char *nl_last_error(void) { return g_err.c_str(); }
 
 const char *nl_version(void) { return "nlstack 0.1.0 (gfx950)"; }
 
+void nl_release_cached_memory(void) { cache_release_all(); }
+
 int nl_device_count(void)
 {
     int n = 0;
@@ -193,16 +269,21 @@ static int destroy_impl(nl_stack_t *h)
     }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->d_frames_owned) (void)hipFree(h->d_frames_owned);
-    if (h->d_out) (void)hipFree(h->d_out);
+    if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    for (int i = 0; i < 2; i++)
+        if (h->chunk_stream[i]) (void)hipStreamSynchronize(h->chunk_stream[i]);
+    // (the large create-time buffers are parked for the next handle of the same geometry, see cached_free)
+    cached_free(h->d_frames_owned, (size_t)h->npix * sizeof(float) * (size_t)h->n_capacity, h->device);
+    cached_free(h->d_out, (size_t)h->npix * sizeof(float), h->device);
     if (h->d_acc) (void)hipFree(h->d_acc);
     if (h->d_weights) (void)hipFree(h->d_weights);
     if (h->d_xstat) (void)hipFree(h->d_xstat);
     if (h->d_sets) (void)hipFree(h->d_sets);
     if (h->d_bounds) (void)hipFree(h->d_bounds);
     if (h->d_nrounds) (void)hipFree(h->d_nrounds);
-    if (h->d_fb_list) (void)hipFree(h->d_fb_list);
-    if (h->d_gen_list) (void)hipFree(h->d_gen_list);
+    cached_free(h->d_fb_list, sizeof(unsigned) * (size_t)h->npix, h->device);
+    cached_free(h->d_gen_list, sizeof(unsigned) * (size_t)h->npix, h->device);
     if (h->d_counters) (void)hipFree(h->d_counters);
     if (h->d_stat_partial) (void)hipFree(h->d_stat_partial);
     if (h->d_ingest) (void)hipFree(h->d_ingest);
@@ -260,9 +341,9 @@ static int create_impl(nl_stack_t *h)
     NL_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     NL_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     const size_t frame_bytes = (size_t)h->npix * sizeof(float);
-    NL_HIP(hipMalloc(&h->d_frames_owned, frame_bytes * (size_t)h->n_frames));
+    NL_HIP(cached_malloc((void **)&h->d_frames_owned, frame_bytes * (size_t)h->n_frames, h->device));
     h->d_frames = h->d_frames_owned;
-    NL_HIP(hipMalloc(&h->d_out, frame_bytes));
+    NL_HIP(cached_malloc((void **)&h->d_out, frame_bytes, h->device));
     NL_HIP(hipMalloc(&h->d_weights, sizeof(float) * (size_t)h->n_frames));
     h->max_grid = 256 * 64;
     NL_HIP(hipMalloc(&h->d_sets, 2 * kScratchBytes));
@@ -271,8 +352,8 @@ static int create_impl(nl_stack_t *h)
     h->d_partial = h->d_sets;
     h->d_fb_count = reinterpret_cast<unsigned *>(h->d_partial + 2 * nl::kClipSlots);
     if (h->npix < (int64_t)0xFFFFFFFFll) {
-        NL_HIP(hipMalloc(&h->d_fb_list, sizeof(unsigned) * (size_t)h->npix));
-        NL_HIP(hipMalloc(&h->d_gen_list, sizeof(unsigned) * (size_t)h->npix));
+        NL_HIP(cached_malloc((void **)&h->d_fb_list, sizeof(unsigned) * (size_t)h->npix, h->device));
+        NL_HIP(cached_malloc((void **)&h->d_gen_list, sizeof(unsigned) * (size_t)h->npix, h->device));
     }
     NL_HIP(hipMalloc(&h->d_counters, sizeof(unsigned long long) * 4));      // {clip_low, clip_high, list lengths (fused passes), -}
     NL_HIP(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * 4, h->stream));

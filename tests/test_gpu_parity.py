@@ -5,7 +5,7 @@ OpStack.Apply, internal/ops/stack/stack.go:156-190."""
 import numpy as np
 import pytest
 
-from util import describe_mismatch, make_frames, same_values
+from util import bits_equal, describe_mismatch, make_frames, same_values
 
 pytestmark = pytest.mark.gpu
 
@@ -774,3 +774,33 @@ def test_device_bytes_reports_the_lazily_allocated_scratch(nl):
         st.set_weights(np.linspace(0.2, 1.0, n).astype(np.float32))
         st.run(2, 3.0, 3.0)
         assert st.device_bytes >= b0 + 65 * w * h
+
+
+def test_destroyed_handles_park_their_buffers_for_the_next_one(nl, oracle):
+    # nl_stack_destroy parks the large buffers, the next handle of the same geometry takes them over (stale contents:
+    # every pass must overwrite what it reads back); nl_release_cached_memory hands them back to HIP
+    import ctypes
+    from nightlight_amd import capi
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    lib.nl_release_cached_memory.restype = None
+    n, w, h = 24, 1024, 512                    # 48 MiB of frames: above the cache's 1 MiB floor
+    lib.nl_release_cached_memory()
+    frames = make_frames(n, w, h, seed=4242)
+    with nl.StackHandle(n, w, h) as st:
+        p0 = st.frames_device_ptr()
+        st.upload_frames(frames)
+        first, cl0, ch0 = st.run(2, 2.5, 2.5)
+    with nl.StackHandle(n, w, h) as st:
+        assert st.frames_device_ptr() == p0    # the parked block
+        st.upload_frames(frames[::-1].copy())   # other contents in the same memory
+        st.run(3, 2.0, 2.0)
+        st.upload_frames(frames)
+        again, cl1, ch1 = st.run(2, 2.5, 2.5)
+    assert (cl0, ch0) == (cl1, ch1) and bits_equal(first, again)
+    rc, want, wl, wh, _ = oracle.stack_apply(2, frames, None, 2.5, 2.5, 0.0, num_cpu=4)
+    assert (cl0, ch0) == (wl, wh) and close_values(first, want)
+    lib.nl_release_cached_memory()
+    with nl.StackHandle(n, w, h) as st:
+        st.upload_frames(frames)
+        third, cl2, ch2 = st.run(2, 2.5, 2.5)
+    assert (cl2, ch2) == (cl0, ch0) and bits_equal(third, first)

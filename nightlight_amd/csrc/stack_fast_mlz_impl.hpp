@@ -59,12 +59,25 @@ struct MlzLayout {
     // a lane is dealt at most NTOP / LPP frames: its positions from there on hold +Inf, the in-lane sort is the
     // network of the next tabulated size (sort_tables.inc: 80, 96, 112, 128)
     static constexpr int NSL = NTOP / LPP <= 80 ? 80 : (NTOP / LPP <= 96 ? 96 : (NTOP / LPP <= 112 ? 112 : 128));
-    static constexpr int BLOCK = mlz_block<LPP>;
-    static constexpr int PW = BLOCK / LPP;                      // pixels per workgroup = LDS row length (64)
+    // Winsorized kernels with four lanes per pixel: workgroups of 128 threads = 32 pixels, whose rounds phase is one
+    // half-filled wave -- half the LDS per workgroup (30 KiB), so that a CU still holds a full complement of waves while
+    // some of its workgroups are down to their rounds wave.  (With 64 pixels per workgroup -- 60 KiB, two workgroups per
+    // CU -- the packed rounds measured 1 - 4 % SLOWER than unpacked ones; with 32: C3 tile kernel 3.98 -> 3.15 ms,
+    // winsorized 300 / 400 frames 6.62 / 6.96 -> 5.12 / 5.50 ms.)
+#ifdef NL_MLZ_SPACK
+    static constexpr int BLOCK = (LPP == 4) ? 128 : mlz_block<LPP>;      // (A/B builds: the sigma kernels, too)
+#else
+    static constexpr int BLOCK = (WINSOR && LPP == 4) ? 128 : mlz_block<LPP>;
+#endif
+    static constexpr int PW = BLOCK / LPP;                      // pixels per workgroup = LDS row length (64 or 32)
     // alive window: a < ZLC, b > NTOP - ZHC; up to PADS missing samples (frames short of NTOP + NaNs)
     static constexpr int ZLC = 16, ZHC = FULL ? 24 : 32, PADS = FULL ? 15 : 23;
     static constexpr int CR = WINSOR ? 16 : 8;                  // ranks read per side and pass for the clip decisions
-    static constexpr int KL = WINSOR ? (LPP == 4 ? 64 : 32) : 24;          // low column : ranks [0, KL)
+    // (winsorized, two lanes per pixel: the clamps sit at +-1.5 sigma, 6.7 % of the samples per side -- 17 +- 4 of 256, and
+    // the low pointer must stay 8 ranks inside the column: with 32 ranks 6.5 % of the pixels of a 256-frame stack went to
+    // the generic pass (550 k of 8.4 M: 3 ms of tail); the class that fills its lanes takes 40.  The other classes of
+    // two lanes would need 41 KiB of LDS with 40 -- three instead of four workgroups per CU.)
+    static constexpr int KL = WINSOR ? (LPP == 4 ? 64 : (FULL ? 40 : 32)) : 24;          // low column : ranks [0, KL)
     static constexpr int KH = (WINSOR ? (LPP == 4 ? 72 : 40) : 32) + (FULL ? 0 : 8);   // high column: ranks [NTOP-KH, NTOP)
     // SELECT: the columns and the median window are SELECTED from the lanes' sorted runs (select_ends / select_window below)
     // instead of read off a full cross-lane merge -- stacks that fill their lanes, plain sigma clipping
@@ -74,12 +87,15 @@ struct MlzLayout {
     // (four lanes per pixel only: with two the full merge is one cross-lane stage and measures 4 % faster)
     static constexpr bool SELECT = FULL && !WINSOR && LPP == 4;
 #endif
-    // PACK: the clipping rounds run in ONE lane per pixel -- one wave for the workgroup's 64 pixels, the others retire
-    // (see the kernel).  Plain sigma clipping only: measured on the winsorized kernels (60 KiB of LDS, two workgroups
-    // per CU) the packed rounds -- 2.6 x fewer instructions -- ran 1 - 4 % SLOWER: their rounds are a chain of dependent
-    // LDS reads, the LPP copies ran side by side on LPP SIMDs, and a workgroup in its rounds still holds its LDS, so the
-    // freed wave slots stay empty (C3 tile 3.95 -> 4.10 ms, winsor 300: 6.53 -> 6.70 ms).
-    static constexpr bool PACK = !WINSOR;
+    // PACK: the clipping rounds run in ONE lane per pixel -- one wave for the workgroup's pixels, the others retire
+    // (see the kernel).  A workgroup in its rounds still holds its LDS: the freed wave slots only fill if the CU has LDS
+    // for more workgroups -- hence the smaller workgroups of the winsorized kernels (BLOCK above); the winsorized kernels
+    // with two lanes per pixel (35 - 39 KiB for 64 pixels in two waves) stay unpacked.
+#ifdef NL_MLZ_W2PACK
+    static constexpr bool PACK = true;                           // (A/B builds: winsorized kernels with two lanes per pixel, too)
+#else
+    static constexpr bool PACK = !WINSOR || LPP == 4;
+#endif
     static constexpr int KE = 32;                               // SELECT: ranks selected per end (>= KL, KH)
     static constexpr int KLS = SELECT ? KE : KL;                // LDS rows of the low column
     static constexpr int GL = KL / 4 + 1, GH = KH / 4 + 1;      // table entries
@@ -465,10 +481,10 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
 
     // ---- rounds phase: PACK: lane = pixel of the workgroup; else every lane of a pixel runs its rounds ----
     const int role = L::PACK ? 0 : (int)(threadIdx.x % LPP);         // (role 0 reports)
-    const int slot_px = L::PACK ? lane : (int)(threadIdx.x / LPP);
+    const int slot_px = L::PACK ? min(lane, PW - 1) : (int)(threadIdx.x / LPP);      // (PW < 64: the upper lanes idle)
     float *col = lds + slot_px;
     const int64_t pix = (int64_t)blockIdx.x * PW + slot_px;
-    const bool on = pix < p.npix;
+    const bool on = pix < p.npix && (!L::PACK || lane < PW);
     const int n = __float_as_int(col[(L::PS + 0) * PW]);
     const float c = col[(L::PS + 1) * PW];
     const float d_fix = col[(L::PS + 2) * PW], q_fix = col[(L::PS + 3) * PW];
@@ -805,9 +821,9 @@ static bool launch_mlz_classes(int ntop, bool winsor, const StackArgs &args, con
         constexpr int NTOP = decltype(C)::value;
         if (done || ntop != NTOP) return;
         using L = MlzLayout<LPP, false, NTOP>;
-        const unsigned blocks = (unsigned)((args.npix + L::PW - 1) / L::PW);
-        if (winsor) hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, true, NTOP>), dim3(blocks), dim3(L::BLOCK), 0, stream, args, f);
-        else        hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, false, NTOP>), dim3(blocks), dim3(L::BLOCK), 0, stream, args, f);
+        using LW = MlzLayout<LPP, true, NTOP>;
+        if (winsor) hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, true, NTOP>), dim3((unsigned)((args.npix + LW::PW - 1) / LW::PW)), dim3(LW::BLOCK), 0, stream, args, f);
+        else        hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, false, NTOP>), dim3((unsigned)((args.npix + L::PW - 1) / L::PW)), dim3(L::BLOCK), 0, stream, args, f);
         done = true;
     };
     (one(std::integral_constant<int, NTOPS>{}), ...);

@@ -188,7 +188,8 @@ int nl_stack_set_exact(nl_stack_t *h, int on);
  * kernel start / end; nl_stack_pass_times then fails with NL_ERR_INVALID_ARG for that pass.  The event at the END of a
  * pass stays: asynchronous uploads order themselves behind it.  tools/wall_probe.py measures what the events cost),
  * bit 6 (64) = no chunked pass even where the environment variable NL_CHUNKS asks for one,
- * bit 7 (128) = winsorized passes of 16 ... 128 frames without the winsorization cascade.
+ * bit 7 (128) = winsorized passes of 16 ... 128 frames without the winsorization cascade,
+ * bit 9 (512) = the first pass on a handle takes no list-length hints from earlier handles of the same geometry.
  * Default 0.  No counterpart in the reference. */
 int nl_stack_set_dev_flags(nl_stack_t *h, unsigned flags);
 /* Pixels of the last pass that were re-done by the exact kernel. */

@@ -139,6 +139,41 @@ void cached_free(void *p, size_t bytes, int device)
     (void)hipFree(p);
 }
 
+// ---- list-length hints across handles ---------------------------------------------------------------------------------
+// A pass sizes its replay grids and picks its protocol from the list lengths the last FINISHED pass on the handle
+// reported.  A handle that lives for one Apply never has one: its pass ran with 16 384-workgroup replay grids and the
+// plain protocol (headline stack: 2.04 instead of 1.73 ms).  The lengths are therefore also remembered per geometry --
+// frames, tile pixels, mode, weighted -- in a small process-wide table: the next handle of that geometry starts from
+// what the last one saw (stacks of one session resemble each other; a wrong hint costs time, never correctness).
+struct HintKey { int frames; int64_t npix; int mode; bool weighted; };
+struct HintEntry { HintKey key; unsigned fb, gen; };
+std::mutex g_hint_mu;
+std::vector<HintEntry> g_hints;
+constexpr size_t kHintEntries = 32;
+
+void hints_store(const HintKey &k, unsigned fb, unsigned gen)
+{
+    std::lock_guard<std::mutex> lk(g_hint_mu);
+    for (HintEntry &e : g_hints)
+        if (e.key.frames == k.frames && e.key.npix == k.npix && e.key.mode == k.mode && e.key.weighted == k.weighted) {
+            e.fb = fb; e.gen = gen;
+            return;
+        }
+    if (g_hints.size() >= kHintEntries) g_hints.erase(g_hints.begin());
+    g_hints.push_back({k, fb, gen});
+}
+
+bool hints_load(const HintKey &k, unsigned *fb, unsigned *gen)
+{
+    std::lock_guard<std::mutex> lk(g_hint_mu);
+    for (const HintEntry &e : g_hints)
+        if (e.key.frames == k.frames && e.key.npix == k.npix && e.key.mode == k.mode && e.key.weighted == k.weighted) {
+            *fb = e.fb; *gen = e.gen;
+            return true;
+        }
+    return false;
+}
+
 int next_pow2(int n)
 {
     int p = 1;
@@ -183,6 +218,7 @@ struct nl_stack {
     bool bounds_tried = false;
     unsigned fb_hint = 0;                      // exact-list length of the last finished fast pass + 1 (0 = unknown)
     unsigned gen_hint = 0;                     // same for the generic list
+    bool last_weighted = false;                // the last pass ran with weights (key of the hints it leaves)
     bool last_fused = false;
     bool last_lists = false;                   // the last pass left its list lengths behind the totals (d_counters[2])
     unsigned dev_flags = 0;                    // nl_stack_set_dev_flags (A/B measurements)
@@ -886,6 +922,11 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
                              nl::fast_ml_supported(mode, weighted, a.n_frames, a.npix));
     // (only while the exact list is short -- the length the last finished pass reported: its replays add their
     // counts to ONE word, and thousands of workgroups doing that take longer than a reduction kernel)
+    if (sigma_fast && h->fb_hint == 0 && !(h->dev_flags & 512u)) {          // (developer switch 512: no hints from other handles)
+        unsigned fb = 0, gen = 0;
+        if (hints_load({a.n_frames, a.npix, mode, weighted}, &fb, &gen)) { h->fb_hint = fb; h->gen_hint = gen; }
+    }
+    h->last_weighted = weighted;
     ChunkPlan plan;
     if (sigma_fast && a.n_frames > 16 && nl::coop_supported(mode, weighted, a.n_frames) != 0) chunk_plan(h, mode, weighted, a.n_frames, &plan);
     const bool chunked = plan.n > 1;
@@ -1376,6 +1417,7 @@ int nl_stack_finish(nl_stack_t *h, float *out_host, int64_t *clip_low, int64_t *
     if (h->last_has_counters && h->last_lists) {
         h->fb_hint = (unsigned)(c[2] & 0xffffffffull) + 1u;
         h->gen_hint = (unsigned)(c[2] >> 32) + 1u;
+        hints_store({h->n_frames, h->npix, h->last_mode, h->last_weighted}, h->fb_hint, h->gen_hint);
     }
     if (clip_low) *clip_low = (int64_t)c[0];
     if (clip_high) *clip_high = (int64_t)c[1];

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         int N = p.n_frames;
         asm volatile("" : "+s"(N));
         const int64_t item = wg_item + threadIdx.x;
-        const bool on = item < limit;
+        bool on = item < limit;
         int64_t pix = item;
         unsigned cas_at = 0;                                 // CONT: where this lane's item sits in the previous stage's list
         if constexpr (CONT) {
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         // Positions [ZL,ZH) are never clipped in the zonal passes, so their
         // share of D and Q is computed once; an iteration only re-sums the zones.
         constexpr int W0 = ZONAL ? ZH / 2 - 1 : 0, W1 = ZONAL ? ZL + NS / 2 + 1 : NS;
-        const float c = pick<W0, W1>(v, a + ((b - a) >> 1));
+        float c = pick<W0, W1>(v, a + ((b - a) >> 1));
         float d_mid = 0.0f, q_mid = 0.0f;
         if constexpr (ZONAL) {
             float d0 = 0, d1 = 0, d2 = 0, d3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
@@ -202,12 +202,13 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
 
         int rnd = 0;                           // RECORD: clipping rounds decided so far
         if (ZONAL && lane == 0) NL_STAT(4, 1);
-        while (__any(active)) {
+        // one clipping pass of every active lane (stack.go:401-431; the winsorized variants with their loop inside)
+        auto one_pass = [&]() NL_INL {
             if constexpr (CASCADE) {
                 if (passes_left <= 0) {                    // whoever needs another pass takes it in the next stage
                     defer = defer || active;
                     active = false;
-                    break;
+                    return;
                 }
                 passes_left--;
             }
@@ -508,14 +509,10 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
                     }
                 }
             }
-        }
-
-        if constexpr (RECORD) {
-            // (a pixel without data is left to the full replay, which writes RefFrameLoc)
-            const bool decided = on && !to_generic && !to_exact && n > 0 && rnd <= kBoundRounds;
-            if (on) p.nrounds[pix] = (unsigned char)(decided ? rnd : 0);
-        } else {
-        if (on && !to_generic && !to_exact && !defer) {
+        };
+        // what a lane that is through leaves behind: its result and counts, or its place on a hand-over / continuation list
+        auto flush = [&]() NL_INL {
+        if (on && !active && !to_generic && !to_exact && !defer) {
             p.out[pix] = res;
             c_lo_total += c_lo;
             c_hi_total += c_hi;
@@ -554,6 +551,24 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
             const unsigned slot = base + (unsigned)__popcll(em & ((1ull << lane) - 1ull));
             if (on && to_exact && slot < q.fb_capacity) q.fb_list[slot] = (unsigned)pix;
         }
+            on = on && active;                         // (whoever is not active any more is done with)
+            to_generic = false;
+            to_exact = false;
+            defer = false;
+        };
+        // (Round 4 also tried an intra-workgroup compaction here for plain sigma clipping: after two clipping passes the
+        // unfinished lanes of the four waves -- a quarter of them -- moved their clip zones, median window and seven
+        // scalars through LDS into one or two packed waves.  A wave runs 4.5 passes where a lane needs 2.0, yet the
+        // barrier, the hand-over and the second copy of the pass body cost more than the saved passes at 100 and 128
+        // frames: headline kernel 1.55 - 1.59 -> 1.67 ms; 48 / 64 frames gained 3 %.  Removed;
+        // profiles/r04_sigma512_experiments.txt.)
+        while (__any(active)) one_pass();
+        if constexpr (RECORD) {
+            // (a pixel without data is left to the full replay, which writes RefFrameLoc)
+            const bool decided = on && !to_generic && !to_exact && n > 0 && rnd <= kBoundRounds;
+            if (on) p.nrounds[pix] = (unsigned char)(decided ? rnd : 0);
+        } else {
+            flush();
         }
     }
     if constexpr (RECORD) return;

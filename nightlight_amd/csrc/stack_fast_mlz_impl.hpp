@@ -331,8 +331,11 @@ __device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0
 
 }  // namespace
 
+#ifndef NL_MLZ_WINSOR_WAVES
+#define NL_MLZ_WINSOR_WAVES 2
+#endif
 template <int LPP, bool WINSOR, int NTOP>
-__global__ __launch_bounds__(mlz_block<LPP>) __attribute__((amdgpu_waves_per_eu(WINSOR ? 2 : 3, 8)))
+__global__ __launch_bounds__(mlz_block<LPP>) __attribute__((amdgpu_waves_per_eu(WINSOR ? NL_MLZ_WINSOR_WAVES : 3, 8)))
 void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
 {
     using L = MlzLayout<LPP, WINSOR, NTOP>;

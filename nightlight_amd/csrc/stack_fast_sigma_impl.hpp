@@ -35,8 +35,21 @@ namespace nl {
 // replayed from scratch as before.
 // CONT (zonal only): the kernel runs over q.in_list / q.in_state instead of the tile.
 
+#ifndef NL_WINSOR_WL
+#define NL_WINSOR_WL(ns) ((ns) >= 112 ? 20 : ((ns) >= 80 ? 16 : ((ns) / 4 + 3) / 4 * 4))
+#endif
+
+// Occupancy.  The winsorized zonal kernels are chains of dependent operations (interval arithmetic, square roots,
+// divisions): a third wave per SIMD is worth a few spilled registers.  The instantiations for stacks of exactly NS frames
+// fit 168 registers anyway (158 / 166 at 112 / 128 positions); the ones with padding (frame counts between the network
+// sizes) took 178 and ran at two waves per SIMD -- 120 frames 8.1 ms where 128 frames take 5.4.
+// The same one step down: 48 ... 96 positions take 118 ... 134 registers for exactly NS frames (133 with padding at 48) -- a
+// fourth wave costs a handful of spills: 64 / 80 / 96 frames dominant kernel -11 / -8 / -6 %, 44 frames -15 %; the padded
+// instantiations of 64 ... 96 positions (155 registers) lose 5 % when forced and stay.
 template <int NS, bool ZONAL, bool WINSOR, bool TIGHT, bool RECORD = false, bool CONT = false>
-__global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu((ZONAL && WINSOR && !RECORD && !CONT) ? (NS >= 112 ? (TIGHT ? 1 : 3) : (NS >= 64 ? (TIGHT ? 4 : 1) : (NS >= 48 ? 4 : 1))) : 1, 8)))
+void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
 {
     static_assert(!TIGHT || ZONAL, "TIGHT is a variant of the zonal kernels");
     static_assert(!RECORD || ZONAL, "RECORD is a variant of the zonal kernels");
@@ -163,9 +176,6 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
         // the inner half contributes these fixed sums
         // (the clamps sit at +-1.5 sigma: 6.7 % of a Gaussian column per side, 8.6 +- 2.8 samples of 128;
         // a pixel with more goes to the replay through shape_ok)
-#ifndef NL_WINSOR_WL
-#define NL_WINSOR_WL(ns) ((ns) >= 112 ? 20 : ((ns) >= 80 ? 16 : ((ns) / 4 + 3) / 4 * 4))
-#endif
         constexpr int WL = ZONAL ? NL_WINSOR_WL(NS) : 0, WH = ZONAL ? NS - WL - KP : NS;
         float d_in = 0.0f, q_in = 0.0f;
         if constexpr (ZONAL && WINSOR) {
@@ -556,12 +566,12 @@ __global__ __launch_bounds__(256) void stack_sigma_fast_kernel(StackArgs p, Fast
             to_exact = false;
             defer = false;
         };
-        // (Round 4 also tried an intra-workgroup compaction here for plain sigma clipping: after two clipping passes the
-        // unfinished lanes of the four waves -- a quarter of them -- moved their clip zones, median window and seven
-        // scalars through LDS into one or two packed waves.  A wave runs 4.5 passes where a lane needs 2.0, yet the
-        // barrier, the hand-over and the second copy of the pass body cost more than the saved passes at 100 and 128
-        // frames: headline kernel 1.55 - 1.59 -> 1.67 ms; 48 / 64 frames gained 3 %.  Removed;
-        // profiles/r04_sigma512_experiments.txt.)
+        // (Round 4 also tried an intra-workgroup compaction here: after two clipping passes the unfinished lanes of the
+        // four waves moved what a pass touches -- clip / clamp zones, median window, a handful of scalars -- through LDS
+        // into one or two packed waves.  A wave runs 4.5 passes where a lane needs 2.0 (sigma, 128 frames; winsorized:
+        // 3.4 passes and 28 winsorization rounds against 1.8 and 9.6), yet plain sigma clipping LOST 6 % at 100 and 128
+        // frames (headline kernel 1.55 - 1.59 -> 1.67 ms; a pass is only 430 instructions) and the winsorized kernels
+        // gained nothing (4.59 -> 4.60 ms).  Removed; profiles/r04_sigma512_experiments.txt.)
         while (__any(active)) one_pass();
         if constexpr (RECORD) {
             // (a pixel without data is left to the full replay, which writes RefFrameLoc)

@@ -1172,7 +1172,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
         // use at the same time); their lengths in the scratch set.  NL_WCAS="b1,b2" sets the budgets, "0" turns it off;
         // developer switch 128: off (A/B inside one process)
         bool cascade = false;
-        if (mode == NL_ST_WINSOR_SIGMA && a.n_frames <= 128 && a.n_frames >= 16 && !(h->dev_flags & 128u)) {
+        if (mode == NL_ST_WINSOR_SIGMA && a.n_frames <= 128 && a.n_frames >= 12 && !(h->dev_flags & 128u)) {
             // plan: "passes:cap[:group]" per stage, comma-separated, the dominant kernel first; the last stage runs to the end
             struct Plan { int stages; int pass[nl::kCascadeStages], cap[nl::kCascadeStages], group[nl::kCascadeStages]; };
             auto parse = [](const char *e, Plan *pl) {

@@ -48,7 +48,7 @@ namespace nl {
 // instantiations of 64 ... 96 positions (155 registers) lose 5 % when forced and stay.
 template <int NS, bool ZONAL, bool WINSOR, bool TIGHT, bool RECORD = false, bool CONT = false>
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu((ZONAL && WINSOR && !RECORD && !CONT) ? (NS >= 112 ? (TIGHT ? 1 : 3) : (NS >= 64 ? (TIGHT ? 4 : 1) : (NS >= 48 ? 4 : 1))) : 1, 8)))
+__attribute__((amdgpu_waves_per_eu((ZONAL && WINSOR && !CONT) ? (NS >= 112 ? (TIGHT ? 1 : 3) : (RECORD ? 1 : (NS >= 64 ? (TIGHT ? 4 : 1) : (NS >= 48 ? 4 : 1)))) : 1, 8)))
 void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
 {
     static_assert(!TIGHT || ZONAL, "TIGHT is a variant of the zonal kernels");
@@ -73,9 +73,13 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
     int64_t sweep = listed ? (int64_t)gridDim.x * blockDim.x : limit;
     int64_t wg_first = (int64_t)blockIdx.x * blockDim.x;
     // CASCADE: this workgroup's continuation region fills through an LDS counter (no device atomics, see FastArgs)
-    __shared__ unsigned s_cont, s_pref[17];
+    __shared__ unsigned s_cont, s_pref[17], s_gen, s_gen_base;
     if constexpr (CASCADE) {
         if (threadIdx.x == 0) s_cont = 0u;
+    }
+    if constexpr (ZONAL && !RECORD) {
+        if (threadIdx.x == 0) s_gen = 0u;
+        __syncthreads();
     }
     if constexpr (CONT) {
         // input: q.in_group consecutive regions of the previous stage's list, first region blockIdx.x * in_group; the
@@ -541,17 +545,25 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
                 }
             }
         }
-        // hand-over lists: one atomic per wave reserves a contiguous run, lanes
-        // fill it in lane order, so the consumer's loads stay coalesced
+        // hand-over lists: a contiguous run per WORKGROUP -- the waves take their places in it through an LDS counter,
+        // one device atomic reserves the run (round 4: one atomic per wave cost 11 ns each, all on one L2 channel -- a
+        // frame count just above a network size sends 1 - 3 % of the pixels here from half of the 262 144 waves: 1.4 ms
+        // of serialised atomics inside a 0.4 ms kernel at 25 frames), lanes fill it in order, so the consumer's loads
+        // stay coalesced
         if constexpr (ZONAL && !RECORD) {
             const unsigned long long gm = __ballot(on && to_generic);
+            unsigned woff = 0;
+            if (lane == 0 && gm) woff = atomicAdd(&s_gen, (unsigned)__popcll(gm));          // LDS
+            __syncthreads();
+            if (threadIdx.x == 0) s_gen_base = s_gen ? atomicAdd(q.gen_count, s_gen) : 0u;
+            __syncthreads();
             if (gm) {
-                unsigned base = 0;
-                if (lane == 0) base = atomicAdd(q.gen_count, (unsigned)__popcll(gm));
-                base = __shfl(base, 0, 64);
+                const unsigned base = s_gen_base + (unsigned)__shfl((int)woff, 0, 64);
                 const unsigned slot = base + (unsigned)__popcll(gm & ((1ull << lane) - 1ull));
                 if (on && to_generic && slot < q.gen_capacity) q.gen_list[slot] = (unsigned)pix;
             }
+            __syncthreads();
+            if (threadIdx.x == 0) s_gen = 0u;                  // (for the next trip of a listed kernel; ordered by the barriers above / below)
         }
         const unsigned long long em = RECORD ? 0ull : __ballot(on && to_exact);
         if (em) {

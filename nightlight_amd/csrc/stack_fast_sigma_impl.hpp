@@ -137,7 +137,10 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
         // clamped samples takes the dead positions in front of the low pointer into account, see n_lo below: without that
         // the padding widened every pixel's interval and 50 times as many went to the exact list)
         if constexpr (ZONAL && !TIGHT) {
-            lo_pads = min(max(KZ / 2 + 1 - (N - ZH), 0), KZ / 2 - 1);     // (N is wave-uniform)
+            // (zones of 4 positions -- 17, 25, 33 frames: one frame above a network size -- split evenly, 2 + 2: with one
+            // pad at the bottom the high zone held two samples and every pixel with two high clips went to the generic
+            // pass -- 1.1 % of them at 25 frames, 187 k, and the appends alone cost the kernel 0.3 ms)
+            lo_pads = min(max(KZ / 2 + 1 - (N - ZH), 0), KZ == 4 ? KZ / 2 : KZ / 2 - 1);     // (N is wave-uniform)
         }
         const int n = gather_sorted<NS, 16, Sorter, true, !TIGHT>(p.frames, p.stride, N, boff, v, lo_pads);
         bool to_exact = false;

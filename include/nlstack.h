@@ -96,6 +96,29 @@ int nl_stack_upload_wait(nl_stack_t *h);
 /* Device address of the planar frame buffer (for in-place producers that
  * already live on the GPU); valid until destroy/attach. */
 void *nl_stack_frames_device_ptr(nl_stack_t *h);
+/* ---- FITS framing (host): where the payload sits in a file image, and the frame around a result ------------------
+ * internal/fits/read.go:445-469 reads the header in 2880-byte units of 80-byte cards up to END; :97-147 take SIMPLE,
+ * BITPIX, NAXIS, NAXISn (mandatory) and BZERO (default 0), BSCALE (default 1), EXPOSURE or else EXPTIME (default 0) from
+ * it.  internal/fits/write.go:54-89 writes SIMPLE, BITPIX -32, NAXIS, NAXISn, BZERO, BSCALE, EXPOSURE (if non-zero),
+ * PROGRAM, END, pads header and payload to 2880 bytes with spaces.  The payload itself is decoded / encoded on the device
+ * (nl_stack_upload_frame_fits, nl_stack_download_result_fits). */
+#define NL_FITS_MAX_AXES 8
+typedef struct nl_fits_header {
+    int32_t bitpix, naxis, naxisn[NL_FITS_MAX_AXES];
+    float bzero, bscale, exposure;
+    int64_t pixels;                  /* product of the axes */
+    int64_t header_bytes;            /* = offset of the payload in the file, a multiple of 2880 */
+    int64_t payload_bytes;           /* pixels * |bitpix| / 8 */
+    int64_t padded_payload_bytes;    /* the same, rounded up to 2880 */
+} nl_fits_header_t;
+/* parses the header at the start of a file image; `id` is the frame number the reference puts in front of its messages */
+int nl_fits_parse_header(const void *file_bytes, int64_t n_bytes, int id, nl_fits_header_t *out);
+/* the header Image.Write emits for a BITPIX -32 image; returns its length (a multiple of 2880; with dst == NULL only
+ * that), -1 on error */
+int64_t nl_fits_write_header(void *dst, int64_t capacity, int naxis, const int32_t *naxisn, float bzero, float bscale,
+                             float exposure);
+int64_t nl_fits_padded_bytes(int64_t payload_bytes);
+
 /* Device memory (bytes) the handle holds right now: the buffers of nl_stack_create plus what passes and upload paths
  * have allocated since and keep until nl_stack_destroy (e.g. 65 bytes per pixel of the tile for the thresholds of the
  * weighted clip modes' decision pass).  The reference sizes its batches to host memory (stackbatches.go:121-187); a

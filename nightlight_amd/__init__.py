@@ -8,6 +8,7 @@ from . import capi  # noqa: F401
 from .capi import (NlError, ST_AUTO, ST_LINEAR_FIT, ST_MAD_SIGMA, ST_MEAN, ST_MEDIAN,  # noqa: F401
                    ST_SIGMA, ST_WINSOR_SIGMA, WEIGHT_EXPOSURE, WEIGHT_INVERSE_HFR,
                    WEIGHT_INVERSE_NOISE, WEIGHT_NONE)
-from .stack import StackGroup, StackHandle, median_filter_3x3, median_filter_mask, weights_from_scalars  # noqa: F401
+from .stack import (StackGroup, StackHandle, fits_padded_bytes, fits_parse_header, fits_write_header,  # noqa: F401
+                    median_filter_3x3, median_filter_mask, weights_from_scalars)
 
 __version__ = "0.1.0"

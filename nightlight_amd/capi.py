@@ -32,6 +32,7 @@ EXPORTS = [
     "nl_last_error", "nl_device_count", "nl_version",
     "nl_stack_create", "nl_stack_destroy",
     "nl_stack_upload_frame", "nl_stack_upload_tile", "nl_stack_upload_frame_async", "nl_stack_upload_wait", "nl_stack_frames_device_ptr", "nl_stack_device_bytes", "nl_release_cached_memory",
+    "nl_fits_parse_header", "nl_fits_write_header", "nl_fits_padded_bytes",
     "nl_stack_attach_device_frames", "nl_stack_fill_synthetic", "nl_stack_download_tile", "nl_stack_download_rows",
     "nl_stack_set_active_frames", "nl_stack_set_weights", "nl_weights_from_scalars",
     "nl_stack_linfit_stage_counts", "nl_stack_run", "nl_stack_run_async", "nl_stack_finish", "nl_stack_result_device_ptr",
@@ -69,6 +70,14 @@ _i64p = C.POINTER(C.c_int64)
 _intp = C.POINTER(C.c_int)
 
 
+class FitsHeader(C.Structure):
+    """nl_fits_header_t (include/nlstack.h)"""
+    _fields_ = [("bitpix", C.c_int32), ("naxis", C.c_int32), ("naxisn", C.c_int32 * 8),
+                ("bzero", C.c_float), ("bscale", C.c_float), ("exposure", C.c_float),
+                ("pixels", C.c_int64), ("header_bytes", C.c_int64), ("payload_bytes", C.c_int64),
+                ("padded_payload_bytes", C.c_int64)]
+
+
 def load():
     """Load libnlstack.so (built in-tree by __graft_entry__.build())."""
     global _lib
@@ -98,6 +107,11 @@ def load():
     L.nl_stack_frames_device_ptr.restype = vp
     L.nl_stack_device_bytes.argtypes = [vp]
     L.nl_stack_device_bytes.restype = C.c_int64
+    L.nl_fits_parse_header.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(FitsHeader)]
+    L.nl_fits_write_header.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(C.c_int32), C.c_float, C.c_float, C.c_float]
+    L.nl_fits_write_header.restype = C.c_int64
+    L.nl_fits_padded_bytes.argtypes = [C.c_int64]
+    L.nl_fits_padded_bytes.restype = C.c_int64
     L.nl_stack_attach_device_frames.argtypes = [vp, vp]
     L.nl_stack_fill_synthetic.argtypes = [vp, C.c_uint64]
     L.nl_stack_set_weights.argtypes = [vp, _f32p]

@@ -413,6 +413,37 @@ class StackGroup:
         return out
 
 
+def fits_parse_header(file_bytes, frame_id=0):
+    """Header of a FITS file image (read.go:445-469, 97-147): dict with bitpix, naxisn, bzero, bscale, exposure,
+    pixels, header_bytes (= offset of the payload), payload_bytes, padded_payload_bytes."""
+    lib = capi.load()
+    buf = np.frombuffer(file_bytes, dtype=np.uint8)
+    h = capi.FitsHeader()
+    capi.check(lib.nl_fits_parse_header(buf.ctypes.data_as(C.c_void_p), buf.size, int(frame_id), C.byref(h)))
+    return {"bitpix": h.bitpix, "naxisn": [h.naxisn[i] for i in range(h.naxis)], "bzero": np.float32(h.bzero),
+            "bscale": np.float32(h.bscale), "exposure": np.float32(h.exposure), "pixels": h.pixels,
+            "header_bytes": h.header_bytes, "payload_bytes": h.payload_bytes,
+            "padded_payload_bytes": h.padded_payload_bytes}
+
+
+def fits_write_header(naxisn, bzero=0.0, bscale=1.0, exposure=0.0):
+    """The header Image.Write emits for a BITPIX -32 image (write.go:54-89), padded to 2880-byte blocks."""
+    lib = capi.load()
+    ax = (C.c_int32 * len(naxisn))(*[int(n) for n in naxisn])
+    n = lib.nl_fits_write_header(None, 0, len(naxisn), ax, float(bzero), float(bscale), float(exposure))
+    if n < 0:
+        raise capi.NlError(capi.ERR_INVALID_ARG, capi.last_error())
+    out = np.empty(n, np.uint8)
+    got = lib.nl_fits_write_header(out.ctypes.data_as(C.c_void_p), n, len(naxisn), ax, float(bzero), float(bscale),
+                                   float(exposure))
+    assert got == n
+    return out.tobytes()
+
+
+def fits_padded_bytes(payload_bytes):
+    return int(capi.load().nl_fits_padded_bytes(int(payload_bytes)))
+
+
 def fits_decode(raw, bitpix, bscale=1.0, bzero=0.0, device=0):
     lib = capi.load()
     raw = np.ascontiguousarray(raw, dtype=np.uint8)

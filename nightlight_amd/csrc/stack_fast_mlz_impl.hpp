@@ -476,12 +476,27 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     }   // ---- end of the sorting phase ----
     if constexpr (L::PACK) {
         __syncthreads();
+#ifdef NL_MLZ_EXP_SORTONLY
+        if (p.npix > 0) return;                            // (timing experiment: the sorting phase alone)
+#endif
         if ((int)(threadIdx.x >> 6) != (int)(blockIdx.x % (L::BLOCK / 64))) return;
+#ifdef NL_MLZ_EXP_PRIO
+        __builtin_amdgcn_s_setprio(NL_MLZ_EXP_PRIO);
+#endif
+#ifdef NL_MLZ_EXP_SLEEP
+        if (p.npix > 0) {                                  // (timing experiment: the rounds wave only holds its slot)
+            for (int i = 0; i < NL_MLZ_EXP_SLEEP; i++) __builtin_amdgcn_s_sleep(127);
+            return;
+        }
+#endif
         // (s_setprio 3 for this wave -- it holds the workgroup's LDS -- measured 0.5 % slower, two interleaved runs)
     } else {
         lds_settle();
     }
 
+#if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
+    const unsigned long long exp_t0 = __builtin_readcyclecounter();      // (timing experiment: cycles of the rounds phase)
+#endif
     // ---- rounds phase: PACK: lane = pixel of the workgroup; else every lane of a pixel runs its rounds ----
     const int role = L::PACK ? 0 : (int)(threadIdx.x % LPP);         // (role 0 reports)
     const int slot_px = L::PACK ? min(lane, PW - 1) : (int)(threadIdx.x / LPP);      // (PW < 64: the upper lanes idle)
@@ -508,29 +523,34 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     bool to_exact = false;
 
     // ---- tables: sums from the inner end of each column outwards, every 4th position ----
+    // (the whole column is read before the first table entry is stored: the compiler cannot move a read of `col` across a
+    // store to it, and four reads per LDS round trip made the tables a third of this phase's latency)
     {
+        float t[KL], th[KH];
+        static_range<0, KL>([&](auto K) NL_INL { t[decltype(K)::value] = col[(L::XL + decltype(K)::value) * PW]; });
+        static_range<0, KH>([&](auto K) NL_INL { th[decltype(K)::value] = col[(L::XH + decltype(K)::value) * PW]; });
+        {
         float s1 = 0.0f, s2 = 0.0f;
         col[(L::SL1 + KL / 4) * PW] = 0.0f;
         col[(L::SL2 + KL / 4) * PW] = 0.0f;
         static_range<0, KL / 4>([&](auto G) NL_INL {
             constexpr int g = KL / 4 - 1 - decltype(G)::value;
             static_range<0, 4>([&](auto U) NL_INL {
-                const float e = col[(L::XL + 4 * g + 3 - decltype(U)::value) * PW] - c;
+                const float e = t[4 * g + 3 - decltype(U)::value] - c;
                 s1 += e;
                 s2 = __builtin_fmaf(e, e, s2);
             });
             col[(L::SL1 + g) * PW] = s1;                   // sum over k >= 4g
             col[(L::SL2 + g) * PW] = s2;
         });
-    }
-    {
+        }
         float s1 = 0.0f, s2 = 0.0f;
         col[(L::SH1 + 0) * PW] = 0.0f;
         col[(L::SH2 + 0) * PW] = 0.0f;
         static_range<0, KH / 4>([&](auto G) NL_INL {
             constexpr int g = decltype(G)::value;
             static_range<0, 4>([&](auto U) NL_INL {
-                const float e = col[(L::XH + 4 * g + decltype(U)::value) * PW] - c;
+                const float e = th[4 * g + decltype(U)::value] - c;
                 s1 += e;
                 s2 = __builtin_fmaf(e, e, s2);
             });
@@ -545,7 +565,14 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     int c_lo = 0, c_hi = 0;
     int rnd = 0;                                           // clipping rounds decided so far (StackArgs::bounds)
     int a = 0, b = n;                                      // survivors = sorted ranks [a, b)
+    // (+8: the means are taken with a hardware reciprocal of the sample count, <= 1 ulp, instead of IEEE divisions --
+    // a round is a chain of dependent operations in ONE wave that holds the workgroup's LDS and wave slots, and the two
+    // divisions and two correctly rounded square roots were a fifth of its instructions)
+#ifdef NL_MLZ_IEEE_ROUNDS
     constexpr float kErrF = (float)(2 * L::ROUNDINGS + 8);
+#else
+    constexpr float kErrF = (float)(2 * L::ROUNDINGS + 16);
+#endif
 
     while (__any(active)) {
         const int cnt = b - a;
@@ -591,9 +618,19 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         }
         const float dsum = (d_fix + dz) + (sl1 + sh1);
         const float qsum = (q_fix + qz) + (sl2 + sh2);
+#ifdef NL_MLZ_IEEE_ROUNDS
+        const float inv_cnt = 1.0f / fcnt;
         const float delta = dsum / fcnt;                   // mean~ - c
+#else
+        const float inv_cnt = __builtin_amdgcn_rcpf(fcnt);
+        const float delta = dsum * inv_cnt;                // mean~ - c
+#endif
         const float m = c + delta;
+#ifdef NL_MLZ_IEEE_ROUNDS
         const float aa = qsum / fcnt;                      // E[(x-c)^2]~
+#else
+        const float aa = qsum * inv_cnt;                   // E[(x-c)^2]~
+#endif
         const float bb = delta * delta;
         const float var = fmaxf(aa - bb, 0.0f);
 
@@ -604,15 +641,21 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         // (factor: the mean's rounding scales with the mean of |e| over the alive samples AND the KL + KH column samples
         // that were taken off again -- by Cauchy-Schwarz its square is at most (1 + 56 / cnt) (aa + q_cancel / cnt),
         // cnt >= 457, and 2 |delta| x <= delta^2 + x^2: (1 + 1.1225) / 2 = 1.062 of the bound without the columns)
-        const float err_o = L::SELECT ? (1.07f * kErrF) * kU * ((aa + bb) + q_cancel / fcnt) : kErrF * kU * (aa + bb);
+        const float err_o = L::SELECT ? (1.07f * kErrF) * kU * ((aa + bb) + q_cancel * inv_cnt) : kErrF * kU * (aa + bb);
         const float eps_r = 1.02f * (fcnt + 8.0f) * kU;
         const float e_m = 1.02f * (fcnt + 2.0f) * kU * amax;
         const float v_up = var + err_o;
         const float v_dn = fmaxf(var - err_o, 0.0f);
         const float v_hi = v_up + v_up * eps_r + e_m * e_m;
         const float v_lo = fmaxf(v_dn - v_dn * eps_r, 0.0f);
+#ifdef NL_MLZ_IEEE_ROUNDS
         float s_max = __fsqrt_rn(v_hi) * (1.0f + 4.0f * kU);
         float s_min = __fsqrt_rn(v_lo) * (1.0f - 4.0f * kU);
+#else
+        // hardware square root: <= 1 ulp = 2u, flushes denormals (the absolute term; a flushed lower end is 0, still a lower end)
+        float s_max = __builtin_amdgcn_sqrtf(v_hi) * (1.0f + 6.0f * kU) + 4.0e-19f;
+        float s_min = __builtin_amdgcn_sqrtf(v_lo) * (1.0f - 6.0f * kU);
+#endif
         bool bail = !(v_hi < 3.0e38f);
 
         if constexpr (WINSOR) {
@@ -622,7 +665,6 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
             // both clamps only tighten inside one loop, so the pointers only move inwards
             WinsorInterval wi;
             wi.start(s_min, s_max);
-            const float inv_cnt = 1.0f / fcnt;
             bool inner = active && !bail;
             int jl = al, jh = bl;
             bool first = true;
@@ -794,6 +836,9 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         c_lo_total += __shfl_xor(c_lo_total, o, 64);
         c_hi_total += __shfl_xor(c_hi_total, o, 64);
     }
+#if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
+    if (lane == 0) { NL_STAT(6, __builtin_readcyclecounter() - exp_t0); NL_STAT(7, 1); }
+#endif
     if constexpr (L::PACK) {
         if (lane == 0) {                                   // (the one wave of the rounds phase)
             unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);

@@ -272,16 +272,33 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
             }
             const float dsum = d_mid + (dz0 + dz1);
             const float qsum = q_mid + (qz0 + qz1);
+            // (the means through a hardware reciprocal of the sample count, <= 1 ulp, and the square roots in hardware, <= 1 ulp:
+            // these are OUR moments and the ends of an interval, not the reference's arithmetic -- the margins below pay for it:
+            // two IEEE divisions and two correctly rounded square roots were 45 of a clipping pass's 540 instructions)
+#ifdef NL_IEEE_PASS
+            const float inv_cnt = 1.0f / fcnt;
             const float delta = dsum / fcnt;             // mean~ - c
+#else
+            const float inv_cnt = __builtin_amdgcn_rcpf(fcnt);
+            const float delta = dsum * inv_cnt;          // mean~ - c
+#endif
             const float m = c + delta;
+#ifdef NL_IEEE_PASS
             const float aa = qsum / fcnt;                // E[(x-c)^2]~
+#else
+            const float aa = qsum * inv_cnt;             // E[(x-c)^2]~
+#endif
             const float bb = delta * delta;
             const float var = fmaxf(aa - bb, 0.0f);
 
             // ---- bracket the reference's stddev ----
             // ours: aa carries <= NS/4+8 roundings per term; bb = delta^2 with delta off by
             // <= (NS/4+7) u mean|e|, and 2|delta| mean|e| <= aa + bb: together <= (NS/2+17) u (aa+bb)
+#ifdef NL_IEEE_PASS
             const float err_o = ((float)(NS / 2 + 24)) * kU * (aa + bb);
+#else
+            const float err_o = ((float)(NS / 2 + 32)) * kU * (aa + bb);     // (+8: the reciprocal's ulp in delta, delta^2 and aa)
+#endif
             // reference: relative gamma_(n+3) on its variance, its mean off by <= e_m
             const float eps_r = 1.02f * (fcnt + 8.0f) * kU;
             const float e_m = 1.02f * (fcnt + 2.0f) * kU * amax;
@@ -289,8 +306,14 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
             const float v_dn = fmaxf(var - err_o, 0.0f);
             const float v_hi = v_up + v_up * eps_r + e_m * e_m;
             const float v_lo = fmaxf(v_dn - v_dn * eps_r, 0.0f);
+#ifdef NL_IEEE_PASS
             float s_max = __fsqrt_rn(v_hi) * (1.0f + 4.0f * kU);
             float s_min = __fsqrt_rn(v_lo) * (1.0f - 4.0f * kU);
+#else
+            // (hardware square root: <= 1 ulp = 2u, flushes denormals -- the absolute term; a flushed lower end is 0)
+            float s_max = __builtin_amdgcn_sqrtf(v_hi) * (1.0f + 6.0f * kU) + 4.0e-19f;
+            float s_min = __builtin_amdgcn_sqrtf(v_lo) * (1.0f - 6.0f * kU);
+#endif
             bool bail = !(v_hi < 3.0e38f);          // overflow / NaN (e.g. an Inf sample): exact kernel
 
             // ---- exact median (qsort.go:68-82): sorted column, position lookup ----
@@ -311,7 +334,6 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
                 const float xmax = pick<PZ, NS>(v, b - 1);
                 WinsorInterval wi;
                 wi.start(s_min, s_max);
-                const float inv_cnt = 1.0f / fcnt;
                 bool inner = active && !bail;
                 int rounds_left = (CASCADE && q.round_cap > 0) ? q.round_cap : 0x7fffffff;
                 while (__any(inner)) {
@@ -380,7 +402,11 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
                     const float wa = ((q0 + q1) + (q2 + q3)) * inv_cnt;      // covered by werr
                     const float wb = wd * wd;
                     wvar = fmaxf(wa - wb, 0.0f);
+#ifdef NL_IEEE_PASS
                     werr = ((float)(NS / 2 + 34)) * kU * (wa + wb);
+#else
+                    werr = ((float)(NS / 2 + 40)) * kU * (wa + wb);
+#endif
                     wmean_c = wd;                                  // mean of the copy, minus c
                     wrms = wa;                                     // E[(copy - c)^2]
                     };

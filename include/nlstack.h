@@ -213,6 +213,8 @@ int nl_stack_set_exact(nl_stack_t *h, int on);
  * bit 6 (64) = no chunked pass even where the environment variable NL_CHUNKS asks for one,
  * bit 7 (128) = winsorized passes of 16 ... 128 frames without the winsorization cascade,
  * bit 9 (512) = the first pass on a handle takes no list-length hints from earlier handles of the same geometry.
+ * bit 10 (1024) = sigma clipping of 497 ... 512 frames as TWO kernels (sorting kernel, then a rounds kernel over columns kept in
+ * device memory, 352 bytes per pixel; also NL_MLZ_SPLIT=1) -- measured slower than the one-kernel pass, DESIGN.md section 5n.
  * Default 0.  No counterpart in the reference. */
 int nl_stack_set_dev_flags(nl_stack_t *h, unsigned flags);
 /* Pixels of the last pass that were re-done by the exact kernel. */

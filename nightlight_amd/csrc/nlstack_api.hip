@@ -225,6 +225,10 @@ struct nl_stack {
     unsigned *d_fb_list = nullptr;             // [npix] pixels the fast kernel handed to the exact kernel
     unsigned *d_fb_count = nullptr;            // [2]: exact-list length, generic-list length (inside d_partial)
     unsigned *d_gen_list = nullptr;            // [npix] pixels zonal waves handed to the generic pass
+    float *d_cols = nullptr;                   // split LDS-column pass (FastArgs::cols): rows of cols_stride floats, allocated on first use
+    size_t cols_bytes = 0;
+    int64_t cols_stride = 0;
+    bool cols_tried = false;
     bool force_exact = false;
     int exact_flavour = 0;            // nl_stack_set_exact argument: 1 = LDS column kernel, 2 = wave-per-pixel replay
     bool last_used_fast = false;
@@ -320,6 +324,7 @@ static int destroy_impl(nl_stack_t *h)
     if (h->d_nrounds) (void)hipFree(h->d_nrounds);
     cached_free(h->d_fb_list, sizeof(unsigned) * (size_t)h->npix, h->device);
     cached_free(h->d_gen_list, sizeof(unsigned) * (size_t)h->npix, h->device);
+    if (h->d_cols) cached_free(h->d_cols, h->cols_bytes, h->device);
     if (h->d_counters) (void)hipFree(h->d_counters);
     if (h->d_stat_partial) (void)hipFree(h->d_stat_partial);
     if (h->d_ingest) (void)hipFree(h->d_ingest);
@@ -595,6 +600,7 @@ int64_t nl_stack_device_bytes(nl_stack_t *h)
     if (h->d_nrounds) b += np;
     if (h->d_fb_list) b += np * 4;
     if (h->d_gen_list) b += np * 4;
+    if (h->d_cols) b += (int64_t)h->cols_bytes;
     if (h->d_counters) b += 32;
     if (h->d_stat_partial) b += 8 * 3 * kStatBlocks;
     if (h->d_stat_partial_async) b += 8 * 3 * kStatBlocks;
@@ -729,6 +735,28 @@ static const nl::LinfitCascade *linfit_cascade(nl_stack_t *h, int lanes_per_pixe
 // unweighted winsorized passes above 128 frames put their decided rounds on record for the list replay: scratch for the
 // thresholds, kBoundRounds * 8 + 1 bytes per pixel of the tile (1.1 GB for 4096^2), allocated by the first pass that
 // wants it and held until the handle is destroyed; nl_stack_device_bytes() reports what a handle holds at any time.  false: off (NL_WDECIDE=0, developer switch 4, allocation failed: those passes then run without it).
+// The split pass of the selected LDS-column kernel (stack_fast_mlz_impl.hpp, FastArgs::cols): 352 bytes per pixel for the
+// columns between the sorting kernel and the rounds kernel.  OFF by default -- measured slower than the one-kernel pass
+// (sigma 512 x 4096^2 10.72 against 10.20 ms); NL_MLZ_SPLIT=1 or developer switch 1024 turn it on.
+static void set_split_cols(nl_stack *h, int mode, int n_frames, nl::FastArgs &f)
+{
+    const int rows = nl::mlz_split_rows(mode, n_frames);
+    static const bool on = [] { const char *e = getenv("NL_MLZ_SPLIT"); return e && e[0] == '1'; }();
+    if (rows == 0 || !(on || (h->dev_flags & 1024u))) return;
+    if (!h->d_cols && !h->cols_tried) {
+        h->cols_tried = true;
+        h->cols_stride = (h->npix + 63) / 64 * 64;
+        h->cols_bytes = (size_t)rows * (size_t)h->cols_stride * sizeof(float);
+        if (cached_malloc((void **)&h->d_cols, h->cols_bytes, h->device) != hipSuccess) {
+            (void)hipGetLastError();
+            h->d_cols = nullptr;
+        }
+    }
+    if (!h->d_cols) return;
+    f.cols = h->d_cols;
+    f.cols_stride = h->cols_stride;
+}
+
 static bool ensure_bounds(nl_stack *h)
 {
     static const bool on = [] { const char *e = getenv("NL_WDECIDE"); return !(e && e[0] == '0'); }();
@@ -1090,6 +1118,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
             f.gen_count = cc + 1;
             f.gen_capacity = (unsigned)len;
             f.gen_hint = h->gen_hint ? (unsigned)((double)(h->gen_hint - 1u) * share * 1.25) + 1u : 0u;
+            if (!weighted) set_split_cols(h, mode, ak.n_frames, f);     // (chunks run one after the other on the pass's stream: one buffer)
             nl::StackArgs e = ak;
             e.list = f.fb_list;
             e.list_count = cc;
@@ -1166,6 +1195,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
         f.in_list = nullptr;
         f.in_count = nullptr;
         f.in_capacity = 0;
+        if (!weighted) set_split_cols(h, mode, a.n_frames, f);
         // winsorized clipping of 16 ... 128 frames: the winsorization cascade (stack_fast_sigma_impl.hpp) -- the dominant
         // kernel and a second stage stop at a budget of rounds per wave and hand their unfinished pixels on, a third
         // stage finishes them.  Lists and states live in the buffers of the linear-fit cascade (same sizes, never in
@@ -1362,6 +1392,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
             nl::FastArgs f;
             memset(&f, 0, sizeof f);
             f.record_only = 1;
+            set_split_cols(h, mode, a.n_frames, f);
             const char *ignored = "";
             NL_HIP(nl::launch_stack_sigma_mlz(a, f, h->stream, &ignored, mode == NL_ST_WINSOR_SIGMA));
         }

@@ -17,6 +17,12 @@ int fast_mlz_supported(int mode, bool weighted, int n_frames)
     return (n_frames > 128 && n_frames <= 512) ? 1 : 0;
 }
 
+// (MlzSplit<MlzLayout<4, false, 512>>::N: low column 24, high column 32, scalars 8, median window 24)
+int mlz_split_rows(int mode, int n_frames)
+{
+    return (mode == NL_ST_SIGMA && n_frames > 496 && n_frames <= 512) ? 88 : 0;
+}
+
 int decide_ml_supported(int mode, int n_frames, int64_t npix)
 {
     return (fast_mlz_supported(mode, false, n_frames) && npix < kFastMaxPixels) ? 1 : 0;

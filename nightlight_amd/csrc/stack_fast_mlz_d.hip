@@ -4,6 +4,8 @@
 
 namespace nl {
 
+static_assert(MlzSplit<MlzLayout<4, false, 512>>::N == 88, "mlz_split_rows() in stack_fast_mlz.hip");
+
 bool launch_mlz_part_d(int ntop, bool winsor, const StackArgs &args, const FastArgs &f, hipStream_t stream)
 {
     return launch_mlz_classes<4>(ntop, winsor, args, f, stream, std::integer_sequence<int, 448, 464, 480, 496, 512>{});

@@ -128,6 +128,18 @@ struct MlzLayout {
     static_assert(!SELECT || (KL <= KE && KH == KE && TOPW <= 14 && BOTW <= 10 && PADS < KE), "selection sizes");
 };
 
+// The split pass of the SELECT class: which LDS rows travel from the sorting kernel to the rounds kernel (FastArgs::cols:
+// one block of N rows x 64 pixels per workgroup, contiguous): the low column's KL ranks, the high column, the per-pixel scalars, the median window.
+template <class L>
+struct MlzSplit {
+    static constexpr int N = L::KL + L::KH + 8 + L::MW;
+    static constexpr int row(int g)
+    {
+        return g < L::KL ? L::XL + g : (g < L::KL + L::KH ? L::XH + (g - L::KL) : (g < L::KL + L::KH + 8 ? L::PS + (g - L::KL - L::KH) : L::XW + (g - L::KL - L::KH - 8)));
+    }
+    __device__ static __forceinline__ int row_rt(int g) { return row(g); }
+};
+
 // ---- DPP minima / maxima: "mine" against the partner lane's "theirs" in ONE instruction ----
 // (inline asm: the compiler's hazard recognizer does not look inside -- a VALU write of a register needs two
 // wait states before a DPP read of it.  Every stage below starts with dpp_stage_begin() and only reads, through
@@ -334,14 +346,19 @@ __device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0
 #ifndef NL_MLZ_WINSOR_WAVES
 #define NL_MLZ_WINSOR_WAVES 2
 #endif
-template <int LPP, bool WINSOR, int NTOP>
-__global__ __launch_bounds__(mlz_block<LPP>) __attribute__((amdgpu_waves_per_eu(WINSOR ? NL_MLZ_WINSOR_WAVES : 3, 8)))
+// PHASE (the SELECT class only, see MlzSplit below): 0 = the whole pass in one kernel; 1 = the sorting phase, whose
+// columns go to FastArgs::cols instead of staying in LDS; 2 = the rounds phase over those columns, one wave per workgroup.
+template <int LPP, bool WINSOR, int NTOP, int PHASE = 0>
+__global__ __launch_bounds__(PHASE == 2 ? 64 : mlz_block<LPP>)
+__attribute__((amdgpu_waves_per_eu(PHASE == 2 ? 1 : (WINSOR ? NL_MLZ_WINSOR_WAVES : 3), 8)))
 void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
 {
     using L = MlzLayout<LPP, WINSOR, NTOP>;
+    using SP = MlzSplit<L>;
+    static_assert(PHASE == 0 || (L::SELECT && L::PACK && L::PW == 64), "the split pass exists for the SELECT class");
     constexpr int NS = L::NS, PW = L::PW, KL = L::KL, KH = L::KH, CR = L::CR, H0 = L::H0, W0 = L::W0;
     __shared__ float lds[L::ROWS * PW];
-    fused_prologue_dominant(p);
+    if constexpr (PHASE != 2) fused_prologue_dominant(p);
 
     // Two phases.  SORTING: LPP lanes per pixel, every wave of the workgroup -- gather, in-lane sort, merge / selection,
     // columns + median window + the moments between the columns to LDS.  ROUNDS: ONE lane per pixel, i.e. one wave for
@@ -352,7 +369,15 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     // by the workgroup index so that a CU's SIMDs share the rounds evenly.
     const int lane = threadIdx.x & 63;
     int c_lo_total = 0, c_hi_total = 0;
-    {   // ---- sorting phase ----
+    if constexpr (PHASE == 2) {
+        // ---- the columns the sorting kernel left: rows of 64 pixels, back to their places in LDS ----
+        const float *src = q.cols + (size_t)blockIdx.x * (size_t)(SP::N * PW) + lane;
+        static_range<0, SP::N>([&](auto G) NL_INL {
+            constexpr int g = decltype(G)::value;
+            lds[SP::row(g) * PW + lane] = src[g * PW];
+        });
+        lds_settle();
+    } else {   // ---- sorting phase ----
     const int role = threadIdx.x % LPP;
     float *col = lds + threadIdx.x / LPP;                  // element r of this pixel: col[r * PW]
     const int64_t pix = (int64_t)blockIdx.x * PW + threadIdx.x / LPP;
@@ -474,7 +499,18 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         col[(L::PS + 7) * PW] = x_in_hi;
     }
     }   // ---- end of the sorting phase ----
-    if constexpr (L::PACK) {
+    if constexpr (PHASE == 1) {
+        // the columns, the window and the scalars of the workgroup's 64 pixels: 256-byte rows, every wave its share
+        __syncthreads();
+        float *dst = q.cols + (size_t)blockIdx.x * (size_t)(SP::N * PW) + lane;
+        static_range<0, (SP::N + 3) / 4>([&](auto G) NL_INL {
+            const int g = 4 * decltype(G)::value + (int)(threadIdx.x >> 6);
+            if (g < SP::N) dst[g * PW] = lds[SP::row_rt(g) * PW + lane];
+        });
+        return;
+    } else if constexpr (PHASE == 2) {
+        // (one wave: nothing to meet)
+    } else if constexpr (L::PACK) {
         __syncthreads();
 #ifdef NL_MLZ_EXP_SORTONLY
         if (p.npix > 0) return;                            // (timing experiment: the sorting phase alone)
@@ -871,6 +907,17 @@ static bool launch_mlz_classes(int ntop, bool winsor, const StackArgs &args, con
         using L = MlzLayout<LPP, false, NTOP>;
         using LW = MlzLayout<LPP, true, NTOP>;
         if (winsor) hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, true, NTOP>), dim3((unsigned)((args.npix + LW::PW - 1) / LW::PW)), dim3(LW::BLOCK), 0, stream, args, f);
+        else if constexpr (L::SELECT) {
+            const dim3 grid((unsigned)((args.npix + L::PW - 1) / L::PW));
+            if (f.cols) {
+                // split pass: the sorting kernel's workgroups retire as a whole (in the one-kernel pass three of a
+                // workgroup's four wave slots idle while its fourth wave runs the rounds), then one wave per 64 pixels
+                hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, false, NTOP, 1>), grid, dim3(L::BLOCK), 0, stream, args, f);
+                hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, false, NTOP, 2>), grid, dim3(64), 0, stream, args, f);
+            } else {
+                hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, false, NTOP>), grid, dim3(L::BLOCK), 0, stream, args, f);
+            }
+        }
         else        hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, false, NTOP>), dim3((unsigned)((args.npix + L::PW - 1) / L::PW)), dim3(L::BLOCK), 0, stream, args, f);
         done = true;
     };

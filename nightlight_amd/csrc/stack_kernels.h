@@ -94,6 +94,12 @@ struct FastArgs {
     int pass_budget, round_cap;   // clipping passes a wave may run in this stage / winsorization rounds per pass (0 = no limit)
     int record_only = 0;          // LDS-column kernels as the DECISION pass of a weighted stack (129 ... 512 frames): no outputs, no
                                   // lists, no counters -- only StackArgs::bounds / nrounds (0 rounds for a pixel they would hand over)
+    // The split pass of the LDS-column kernel whose columns are selected (497 ... 512 frames, plain sigma; stack_fast_mlz_impl.hpp):
+    // the sorting kernel leaves mlz_split_rows() rows x 64 pixels per workgroup here (blocks of 64 pixels, contiguous; cols_stride =
+    // pixels the buffer holds, a multiple of 64) and a second kernel, one wave per block, runs the clipping rounds over them.
+    // nullptr: one kernel does both.
+    float *cols = nullptr;
+    long long cols_stride = 0;
 };
 
 // sets what nl_last_error() returns on this thread (nlstack_api.hip)
@@ -213,6 +219,8 @@ typedef void (*AfterDominant)(void *user);
 hipError_t launch_stack_sigma_mlg(const StackArgs &args, const FastArgs &fargs, unsigned grid, hipStream_t stream,
                                   bool winsor);
 int fast_mlz_supported(int mode, bool weighted, int n_frames);
+// rows per pixel the split pass of this mode / frame count keeps in FastArgs::cols (0: the pass is not split)
+int mlz_split_rows(int mode, int n_frames);
 hipError_t launch_stack_sigma_mlz(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name,
                                   bool winsor);
 // tail (optional): the stream the generic pass is launched on instead of `stream` -- chunked passes

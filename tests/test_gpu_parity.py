@@ -761,6 +761,37 @@ def test_developer_switches_do_not_change_results(nl, oracle, mode, n, weighted)
             assert np.array_equal(got.view(np.uint32), ref[0].view(np.uint32)), flags
 
 
+@pytest.mark.parametrize("n,weighted,height", [(512, False, 12), (500, False, 9), (512, True, 6)])
+def test_split_lds_column_pass_gives_the_bits_of_the_one_kernel_pass(nl, oracle, n, weighted, height):
+    # developer switch 1024: the selected LDS-column kernel (497 ... 512 frames, plain sigma) as a sorting kernel plus a
+    # rounds kernel over columns kept in device memory (FastArgs::cols) -- same code for the rounds, so the same bits,
+    # counters and hand-over lists; a ragged last workgroup (height * width not a multiple of 64) included
+    width = 4096 if height != 9 else 1000
+    with nl.StackHandle(n, width, 4096, row0=0, rows=height) as st:
+        st.fill_synthetic(9)
+        if weighted:
+            st.set_weights(np.random.default_rng(n).uniform(0.2, 1.0, n).astype(np.float32))
+        ref = None
+        b0 = None
+        for flags in (0, 1024, 1024 | 1, 0):
+            st.set_dev_flags(flags)
+            got, cl, ch = st.run(2, 3.0, 2.5)
+            got = got[:height * width]
+            if ref is None:
+                ref = (got.copy(), cl, ch, st.last_generic_pixels, st.last_fallback_pixels)
+                b0 = st.device_bytes
+            assert (cl, ch) == ref[1:3], (flags, cl, ch, ref[1:3])
+            assert np.array_equal(got.view(np.uint32), ref[0].view(np.uint32)), flags
+            if not weighted:
+                assert (st.last_generic_pixels, st.last_fallback_pixels) == ref[3:], flags
+        assert st.device_bytes >= b0 + 88 * 4 * height * width          # the columns' buffer is on the books
+        if not weighted:
+            frames = [st.download_tile(i) for i in range(n)]
+            rc, want, wl, wh, _ = oracle.stack_apply(2, frames, None, 3.0, 2.5)
+            assert (wl, wh) == ref[1:3]
+            assert np.allclose(ref[0], want[:height * width], rtol=1e-5, atol=0)
+
+
 def test_device_bytes_reports_the_lazily_allocated_scratch(nl):
     # nl_stack_device_bytes: create-time buffers, then the decision-pass thresholds a weighted clip mode allocates
     # on its first pass (65 bytes per pixel) and keeps until destroy

@@ -215,6 +215,8 @@ int nl_stack_set_exact(nl_stack_t *h, int on);
  * bit 9 (512) = the first pass on a handle takes no list-length hints from earlier handles of the same geometry.
  * bit 10 (1024) = sigma clipping of 497 ... 512 frames as TWO kernels (sorting kernel, then a rounds kernel over columns kept in
  * device memory, 352 bytes per pixel; also NL_MLZ_SPLIT=1) -- measured slower than the one-kernel pass, DESIGN.md section 5n.
+ * bit 11 (2048) = the same class with persistent workgroups (three per CU looping over blocks of 64 pixels, no barrier: a block's
+ * rounds run in one wave while the others sort the next block; also NL_MLZ_PERSIST=1) -- slower as well, same section.
  * Default 0.  No counterpart in the reference. */
 int nl_stack_set_dev_flags(nl_stack_t *h, unsigned flags);
 /* Pixels of the last pass that were re-done by the exact kernel. */

@@ -742,6 +742,10 @@ static void set_split_cols(nl_stack *h, int mode, int n_frames, nl::FastArgs &f)
 {
     const int rows = nl::mlz_split_rows(mode, n_frames);
     static const bool on = [] { const char *e = getenv("NL_MLZ_SPLIT"); return e && e[0] == '1'; }();
+    // (the same class as persistent workgroups -- three per CU, no barrier, the rounds of a block behind the sorting of the
+    // next: also built, also slower; NL_MLZ_PERSIST=1 / developer switch 2048)
+    static const bool persist = [] { const char *e = getenv("NL_MLZ_PERSIST"); return e && e[0] == '1'; }();
+    if (rows != 0 && (persist || (h->dev_flags & 2048u)) && !(h->dev_flags & 1024u)) f.persistent = 1;
     if (rows == 0 || !(on || (h->dev_flags & 1024u))) return;
     if (!h->d_cols && !h->cols_tried) {
         h->cols_tried = true;

@@ -140,6 +140,23 @@ struct MlzSplit {
     __device__ static __forceinline__ int row_rt(int g) { return row(g); }
 };
 
+// Where the rounds phase finds its rows.  MlzRows: the layout above, tables beside the columns (`tab` = `col`).
+// MlzRowsPersistent (PHASE 3, the SELECT class): a compact buffer per block -- the KL / KH ranks of the columns the rounds
+// read, the median window, the scalars and one TRASH row for what the selection stores beyond them (ranks KL .. KE-1 of the
+// low end, the spare window slots) -- of which a workgroup holds TWO, and one table area shared by its rounds.
+template <class L>
+struct MlzRows {
+    static constexpr int XL = L::XL, XH = L::XH, XW = L::XW, PS = L::PS, SL1 = L::SL1, SL2 = L::SL2, SH1 = L::SH1, SH2 = L::SH2;
+    static constexpr int TRASH = -1, ROWS = L::ROWS, TROWS = 0;
+};
+template <class L>
+struct MlzRowsPersistent {
+    // (TRASH: the seventh scalar row -- only the winsorized kernels have a seventh scalar.  LDS is handed out in granules
+    // of 1 280 bytes: with one more row per buffer a workgroup took 43 instead of 42 of them and a CU held two workgroups, not three)
+    static constexpr int XL = 0, XH = XL + L::KL, XW = XH + L::KH, PS = XW + L::MW, TRASH = PS + 6, ROWS = PS + 8;
+    static constexpr int SL1 = 0, SL2 = SL1 + L::GL, SH1 = SL2 + L::GL, SH2 = SH1 + L::GH, TROWS = SH2 + L::GH;
+};
+
 // ---- DPP minima / maxima: "mine" against the partner lane's "theirs" in ONE instruction ----
 // (inline asm: the compiler's hazard recognizer does not look inside -- a VALU write of a register needs two
 // wait states before a DPP read of it.  Every stage below starts with dpp_stage_begin() and only reads, through
@@ -199,7 +216,7 @@ __device__ __forceinline__ void clean_raw(float (&x)[N])
 //     afterwards (its magnitude is the bulk's, not an outlier's: no cancellation to speak of; the extra
 //     rounding is covered by q_cancel in the error bound).
 // Cost: about 1 700 instructions instead of 2 500 for merge + staging + masked moments.
-template <class L, int LPP, int NS>
+template <class L, int LPP, int NS, class V = MlzRows<L>>
 __device__ __forceinline__ void select_ends(const float (&v)[NS], int role, float *col, float &t_lo, float &t_hi)
 {
     constexpr int PW = L::PW, KE = L::KE;
@@ -225,11 +242,13 @@ __device__ __forceinline__ void select_ends(const float (&v)[NS], int role, floa
         run_network<FusedBitonic<KE, 0>, KE>(z);
     }
     // even lanes: z[i] = rank i; odd lanes: z[i] = -(rank NTOP-1-i).  Rows: low column XL + i, high column XH + KE-1-i
-    float *dst = col + (odd ? (L::XH + KE - 1) * PW : L::XL * PW);
+    float *dst = col + (odd ? (V::XH + KE - 1) * PW : V::XL * PW);
     const int step = odd ? -PW : PW;
     static_range<0, KE>([&](auto I) NL_INL {
         constexpr int i = decltype(I)::value;
-        dst[i * step] = __int_as_float(__float_as_int(z[i]) ^ sgn);
+        float *at = dst + i * step;
+        if constexpr (V::TRASH >= 0 && i >= L::KL) at = odd ? at : col + V::TRASH * PW;      // (no row for the low ranks KL .. KE-1)
+        *at = __int_as_float(__float_as_int(z[i]) ^ sgn);
     });
     // innermost column values, in every lane of the pixel
     const float tl = z[L::KL - 1];                                              // rank KL-1 (even lanes)
@@ -239,7 +258,7 @@ __device__ __forceinline__ void select_ends(const float (&v)[NS], int role, floa
 }
 
 // the median window; consumes the runs' middles (v is dead afterwards)
-template <class L, int LPP, int NS>
+template <class L, int LPP, int NS, class V = MlzRows<L>>
 __device__ __forceinline__ void select_window(float (&v)[NS], int role, float *col, bool &window_ok)
 {
     constexpr int PW = L::PW;
@@ -318,11 +337,14 @@ __device__ __forceinline__ void select_window(float (&v)[NS], int role, float *c
     // plain lanes: w[j] = candidate rank (LPP * 32 - 16) + j, i.e. window slot j - 2 for j >= 2; the other lanes:
     // w[j] = -(candidate rank LPP * 32 + 15 - j), window slot 14 + 15 - j (slots up to MW - 1: j >= 6).  The rows
     // outside the window are spare (MlzLayout).
-    float *dst = col + (odd ? (L::XW + 29) * PW : (L::XW - 2) * PW);
+    float *dst = col + (odd ? (V::XW + 29) * PW : (V::XW - 2) * PW);
     const int step = odd ? -PW : PW;
     static_range<0, 16>([&](auto J) NL_INL {
         constexpr int j = decltype(J)::value;
-        dst[j * step] = __int_as_float(__float_as_int(w[j]) ^ sgn);
+        float *at = dst + j * step;
+        if constexpr (V::TRASH >= 0 && j < 2) at = col + V::TRASH * PW;                      // (slots -2, -1 / 29, 28: spare)
+        else if constexpr (V::TRASH >= 0 && j < 6) at = odd ? col + V::TRASH * PW : at;      // (slots 27 .. 24: spare)
+        *at = __int_as_float(__float_as_int(w[j]) ^ sgn);
     });
     // window slot 0 must not be below `below`, slot MW-1 not above `above`
     const float w_first = __int_as_float(quad_bcast<LPP, 0>(__float_as_int(w[2])));
@@ -343,11 +365,25 @@ __device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0
 
 }  // namespace
 
+#ifndef NL_MLZ_STAGGER
+#define NL_MLZ_STAGGER 3        // x 8 128 cycles per third of the grid
+#endif
 #ifndef NL_MLZ_WINSOR_WAVES
 #define NL_MLZ_WINSOR_WAVES 2
 #endif
 // PHASE (the SELECT class only, see MlzSplit below): 0 = the whole pass in one kernel; 1 = the sorting phase, whose
 // columns go to FastArgs::cols instead of staying in LDS; 2 = the rounds phase over those columns, one wave per workgroup.
+// PHASE 3: a wave waits for a flag of its workgroup.  (In practice the flag is long set; a wait that never ends -- a bug --
+// traps instead of hanging the device.)
+__device__ __forceinline__ void mlz_spin_until(unsigned *flag, unsigned target)
+{
+    for (int i = 0; i < (1 << 22); i++) {
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_trap();
+}
+
 template <int LPP, bool WINSOR, int NTOP, int PHASE = 0>
 __global__ __launch_bounds__(PHASE == 2 ? 64 : mlz_block<LPP>)
 __attribute__((amdgpu_waves_per_eu(PHASE == 2 ? 1 : (WINSOR ? NL_MLZ_WINSOR_WAVES : 3), 8)))
@@ -355,9 +391,14 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
 {
     using L = MlzLayout<LPP, WINSOR, NTOP>;
     using SP = MlzSplit<L>;
-    static_assert(PHASE == 0 || (L::SELECT && L::PACK && L::PW == 64), "the split pass exists for the SELECT class");
+    using V = std::conditional_t<PHASE == 3, MlzRowsPersistent<L>, MlzRows<L>>;
+    static_assert(PHASE == 0 || (L::SELECT && L::PACK && L::PW == 64), "the split and the persistent pass exist for the SELECT class");
+    static_assert(PHASE != 3 || (!WINSOR && (2 * V::ROWS + V::TROWS) * L::PW * 4 + 64 <= 42 * 1280), "persistent pass: three workgroups per CU");
     constexpr int NS = L::NS, PW = L::PW, KL = L::KL, KH = L::KH, CR = L::CR, H0 = L::H0, W0 = L::W0;
-    __shared__ float lds[L::ROWS * PW];
+    // (PHASE 3: two column buffers and one table area)
+    __shared__ float lds[(PHASE == 3 ? 2 * V::ROWS + V::TROWS : L::ROWS) * PW];
+    __shared__ unsigned s_done[2], s_freed[2];             // PHASE 3: waves that wrote / rounds that finished, per buffer
+    __shared__ int s_lo[4], s_hi[4];                       // (kernels whose rounds run in every wave: their clip counts)
     if constexpr (PHASE != 2) fused_prologue_dominant(p);
 
     // Two phases.  SORTING: LPP lanes per pixel, every wave of the workgroup -- gather, in-lane sort, merge / selection,
@@ -368,21 +409,21 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     // a fifth (sigma) to a half (winsorized) of the kernel's instructions were those.  The wave that stays is picked
     // by the workgroup index so that a CU's SIMDs share the rounds evenly.
     const int lane = threadIdx.x & 63;
-    int c_lo_total = 0, c_hi_total = 0;
-    if constexpr (PHASE == 2) {
-        // ---- the columns the sorting kernel left: rows of 64 pixels, back to their places in LDS ----
-        const float *src = q.cols + (size_t)blockIdx.x * (size_t)(SP::N * PW) + lane;
-        static_range<0, SP::N>([&](auto G) NL_INL {
-            constexpr int g = decltype(G)::value;
-            lds[SP::row(g) * PW + lane] = src[g * PW];
-        });
-        lds_settle();
-    } else {   // ---- sorting phase ----
-    const int role = threadIdx.x % LPP;
-    float *col = lds + threadIdx.x / LPP;                  // element r of this pixel: col[r * PW]
-    const int64_t pix = (int64_t)blockIdx.x * PW + threadIdx.x / LPP;
+    // ---- sorting phase of block `blk` (PW pixels); its rows go to `colbase`; `before_store` runs in front of the first store ----
+    auto sorting_phase = [&](const int64_t blk, float *const colbase, auto &&before_store) NL_INL {
+    // (PHASE 3 runs this in a loop: everything derived from the thread index would be hoisted out of it -- some thirty
+    // registers, i.e. spills to scratch and their reloads on the waves' critical path (measured: 17.9 instead of 10.1 ms) --
+    // so the index goes through an opaque register per trip and the few shifts and masks are redone)
+    int tid = (int)threadIdx.x;
+    if constexpr (PHASE == 3) asm volatile("" : "+v"(tid));
+    const int role = tid % LPP;
+    float *col = colbase + tid / LPP;                      // element r of this pixel: col[r * PW]
+    const int64_t pix = blk * PW + tid / LPP;
     const bool on = pix < p.npix;
     int N = p.n_frames;
+    // (PHASE 3 calls this in a loop: re-read through an opaque register, or the per-frame scalar selects that depend on the
+    // frame count are hoisted out of the loop and spilled)
+    if constexpr (PHASE == 3) asm volatile("" : "+s"(N));
     float v[NS];
     // a stack that fills its lanes: the last merge orders the 32 lowest / highest ranks of every lane
     // (columns of the plain sigma kernel, median window); the winsorized columns are longer, and the
@@ -411,7 +452,8 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         // shift: the middle of the first lane's run (any value near the bulk works)
         c_sel = bcast_f(std::integral_constant<int, 0>{}, v[NS / 2]);
         float t_lo, t_hi;                                  // innermost values of the low / high column
-        select_ends<L, LPP, NS>(v, role, col, t_lo, t_hi);
+        before_store();
+        select_ends<L, LPP, NS, V>(v, role, col, t_lo, t_hi);
         // moments of every sample of the pixel, the ends of the runs clamped to [t_lo, t_hi]: the KL + KH samples
         // of the columns count as t_lo / t_hi (a missing sample, +Inf, as t_hi) and are taken off again
         {
@@ -438,25 +480,26 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
             d_fix = d_all - ((float)KL * e_lo + (float)KH * e_hi);
             q_fix = q_all - q_cancel;
         }
-        select_window<L, LPP, NS>(v, role, col, window_ok);
+        select_window<L, LPP, NS, V>(v, role, col, window_ok);
     } else {
+    before_store();
     static_range<0, KL>([&](auto K) NL_INL {
         constexpr int k = decltype(K)::value;
-        col[(L::XL + k) * PW] = bcast_f(std::integral_constant<int, 0>{}, v[k]);
+        col[(V::XL + k) * PW] = bcast_f(std::integral_constant<int, 0>{}, v[k]);
     });
     static_range<0, KH>([&](auto K) NL_INL {                          // rank H0 + k: lane rank / NS, register rank % NS
         constexpr int k = decltype(K)::value, r = H0 + k;
-        col[(L::XH + k) * PW] = bcast_f(std::integral_constant<int, r / NS>{}, v[r % NS]);
+        col[(V::XH + k) * PW] = bcast_f(std::integral_constant<int, r / NS>{}, v[r % NS]);
     });
     static_range<0, L::MW>([&](auto K) NL_INL {
         constexpr int k = decltype(K)::value, r = W0 + k;
-        col[(L::XW + k) * PW] = bcast_f(std::integral_constant<int, r / NS>{}, v[r % NS]);
+        col[(V::XW + k) * PW] = bcast_f(std::integral_constant<int, r / NS>{}, v[r % NS]);
     });
     }
     lds_settle();
 
     // shift c = first-pass median (any value near the bulk works)
-    float c = col[(L::XW + min(max((n >> 1) - W0, 0), L::MW - 1)) * PW];
+    float c = col[(V::XW + min(max((n >> 1) - W0, 0), L::MW - 1)) * PW];
     if constexpr (L::SELECT) c = c_sel;
 
     // ---- moments of the ranks between the columns (never clipped, never clamped) ----
@@ -488,66 +531,43 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         x_in_hi = bcast_f(std::integral_constant<int, (H0 - 1) / NS>{}, v[(H0 - 1) % NS]);
     }
     // the pixel's scalars for the rounds phase (every lane of the pixel stores the same values)
-    col[(L::PS + 0) * PW] = __int_as_float(n);
-    col[(L::PS + 1) * PW] = c;
-    col[(L::PS + 2) * PW] = d_fix;
-    col[(L::PS + 3) * PW] = q_fix;
-    col[(L::PS + 4) * PW] = q_cancel;
-    col[(L::PS + 5) * PW] = __int_as_float(window_ok ? 1 : 0);
+    col[(V::PS + 0) * PW] = __int_as_float(n);
+    col[(V::PS + 1) * PW] = c;
+    col[(V::PS + 2) * PW] = d_fix;
+    col[(V::PS + 3) * PW] = q_fix;
+    col[(V::PS + 4) * PW] = q_cancel;
+    col[(V::PS + 5) * PW] = __int_as_float(window_ok ? 1 : 0);
     if constexpr (WINSOR) {
-        col[(L::PS + 6) * PW] = x_in_lo;
-        col[(L::PS + 7) * PW] = x_in_hi;
+        col[(V::PS + 6) * PW] = x_in_lo;
+        col[(V::PS + 7) * PW] = x_in_hi;
     }
-    }   // ---- end of the sorting phase ----
-    if constexpr (PHASE == 1) {
-        // the columns, the window and the scalars of the workgroup's 64 pixels: 256-byte rows, every wave its share
-        __syncthreads();
-        float *dst = q.cols + (size_t)blockIdx.x * (size_t)(SP::N * PW) + lane;
-        static_range<0, (SP::N + 3) / 4>([&](auto G) NL_INL {
-            const int g = 4 * decltype(G)::value + (int)(threadIdx.x >> 6);
-            if (g < SP::N) dst[g * PW] = lds[SP::row_rt(g) * PW + lane];
-        });
-        return;
-    } else if constexpr (PHASE == 2) {
-        // (one wave: nothing to meet)
-    } else if constexpr (L::PACK) {
-        __syncthreads();
-#ifdef NL_MLZ_EXP_SORTONLY
-        if (p.npix > 0) return;                            // (timing experiment: the sorting phase alone)
-#endif
-        if ((int)(threadIdx.x >> 6) != (int)(blockIdx.x % (L::BLOCK / 64))) return;
-#ifdef NL_MLZ_EXP_PRIO
-        __builtin_amdgcn_s_setprio(NL_MLZ_EXP_PRIO);
-#endif
-#ifdef NL_MLZ_EXP_SLEEP
-        if (p.npix > 0) {                                  // (timing experiment: the rounds wave only holds its slot)
-            for (int i = 0; i < NL_MLZ_EXP_SLEEP; i++) __builtin_amdgcn_s_sleep(127);
-            return;
-        }
-#endif
-        // (s_setprio 3 for this wave -- it holds the workgroup's LDS -- measured 0.5 % slower, two interleaved runs)
-    } else {
-        lds_settle();
-    }
+    };   // ---- end of the sorting phase ----
 
+    // ---- rounds phase of block `blk`: columns at `colbase`, tables at `tabbase` ----
+    auto rounds_phase = [&](const int64_t blk, float *const colbase, float *const tabbase) NL_INL {
+    int c_lo_total = 0, c_hi_total = 0;
+    int tid = (int)threadIdx.x;
+    if constexpr (PHASE == 3) asm volatile("" : "+v"(tid));        // (see the sorting phase)
+    const int lane = tid & 63;
 #if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
     const unsigned long long exp_t0 = __builtin_readcyclecounter();      // (timing experiment: cycles of the rounds phase)
 #endif
     // ---- rounds phase: PACK: lane = pixel of the workgroup; else every lane of a pixel runs its rounds ----
     const int role = L::PACK ? 0 : (int)(threadIdx.x % LPP);         // (role 0 reports)
     const int slot_px = L::PACK ? min(lane, PW - 1) : (int)(threadIdx.x / LPP);      // (PW < 64: the upper lanes idle)
-    float *col = lds + slot_px;
-    const int64_t pix = (int64_t)blockIdx.x * PW + slot_px;
+    float *col = colbase + slot_px;
+    float *tab = tabbase + slot_px;                        // (the tables: beside the columns, or the workgroup's table area)
+    const int64_t pix = blk * PW + slot_px;
     const bool on = pix < p.npix && (!L::PACK || lane < PW);
-    const int n = __float_as_int(col[(L::PS + 0) * PW]);
-    const float c = col[(L::PS + 1) * PW];
-    const float d_fix = col[(L::PS + 2) * PW], q_fix = col[(L::PS + 3) * PW];
-    const float q_cancel = col[(L::PS + 4) * PW];
-    const bool window_ok = __float_as_int(col[(L::PS + 5) * PW]) != 0;
+    const int n = __float_as_int(col[(V::PS + 0) * PW]);
+    const float c = col[(V::PS + 1) * PW];
+    const float d_fix = col[(V::PS + 2) * PW], q_fix = col[(V::PS + 3) * PW];
+    const float q_cancel = col[(V::PS + 4) * PW];
+    const bool window_ok = __float_as_int(col[(V::PS + 5) * PW]) != 0;
     float x_in_lo = 0.0f, x_in_hi = 0.0f;
     if constexpr (WINSOR) {
-        x_in_lo = col[(L::PS + 6) * PW];
-        x_in_hi = col[(L::PS + 7) * PW];
+        x_in_lo = col[(V::PS + 6) * PW];
+        x_in_hi = col[(V::PS + 7) * PW];
     }
 
     bool active = on && n > 0;
@@ -563,12 +583,12 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     // store to it, and four reads per LDS round trip made the tables a third of this phase's latency)
     {
         float t[KL], th[KH];
-        static_range<0, KL>([&](auto K) NL_INL { t[decltype(K)::value] = col[(L::XL + decltype(K)::value) * PW]; });
-        static_range<0, KH>([&](auto K) NL_INL { th[decltype(K)::value] = col[(L::XH + decltype(K)::value) * PW]; });
+        static_range<0, KL>([&](auto K) NL_INL { t[decltype(K)::value] = col[(V::XL + decltype(K)::value) * PW]; });
+        static_range<0, KH>([&](auto K) NL_INL { th[decltype(K)::value] = col[(V::XH + decltype(K)::value) * PW]; });
         {
         float s1 = 0.0f, s2 = 0.0f;
-        col[(L::SL1 + KL / 4) * PW] = 0.0f;
-        col[(L::SL2 + KL / 4) * PW] = 0.0f;
+        tab[(V::SL1 + KL / 4) * PW] = 0.0f;
+        tab[(V::SL2 + KL / 4) * PW] = 0.0f;
         static_range<0, KL / 4>([&](auto G) NL_INL {
             constexpr int g = KL / 4 - 1 - decltype(G)::value;
             static_range<0, 4>([&](auto U) NL_INL {
@@ -576,13 +596,13 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
                 s1 += e;
                 s2 = __builtin_fmaf(e, e, s2);
             });
-            col[(L::SL1 + g) * PW] = s1;                   // sum over k >= 4g
-            col[(L::SL2 + g) * PW] = s2;
+            tab[(V::SL1 + g) * PW] = s1;                   // sum over k >= 4g
+            tab[(V::SL2 + g) * PW] = s2;
         });
         }
         float s1 = 0.0f, s2 = 0.0f;
-        col[(L::SH1 + 0) * PW] = 0.0f;
-        col[(L::SH2 + 0) * PW] = 0.0f;
+        tab[(V::SH1 + 0) * PW] = 0.0f;
+        tab[(V::SH2 + 0) * PW] = 0.0f;
         static_range<0, KH / 4>([&](auto G) NL_INL {
             constexpr int g = decltype(G)::value;
             static_range<0, 4>([&](auto U) NL_INL {
@@ -591,8 +611,8 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
                 s2 = __builtin_fmaf(e, e, s2);
             });
             // sum over local t < 4(g+1); missing samples (+Inf) only reach entries that are never read (4g' <= b)
-            col[(L::SH1 + g + 1) * PW] = s1;
-            col[(L::SH2 + g + 1) * PW] = s2;
+            tab[(V::SH1 + g + 1) * PW] = s1;
+            tab[(V::SH2 + g + 1) * PW] = s2;
         });
     }
     lds_settle();
@@ -619,19 +639,19 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         // the tables, the median ----
         float xl[CR], xh[CR];
         {
-            const float *pl = col + (L::XL + al) * PW;
-            const float *ph = col + (L::XH + bl - 1) * PW;
+            const float *pl = col + (V::XL + al) * PW;
+            const float *ph = col + (V::XH + bl - 1) * PW;
             static_range<0, CR>([&](auto I) NL_INL {
                 xl[decltype(I)::value] = pl[decltype(I)::value * PW];
                 xh[decltype(I)::value] = *(ph - decltype(I)::value * PW);
             });
         }
         const int ga = al >> 2, gb = bl >> 2;
-        const float sl1 = col[(L::SL1 + ga + 1) * PW], sl2 = col[(L::SL2 + ga + 1) * PW];
-        const float sh1 = col[(L::SH1 + gb) * PW], sh2 = col[(L::SH2 + gb) * PW];
+        const float sl1 = tab[(V::SL1 + ga + 1) * PW], sl2 = tab[(V::SL2 + ga + 1) * PW];
+        const float sh1 = tab[(V::SH1 + gb) * PW], sh2 = tab[(V::SH2 + gb) * PW];
         const int kk = a + (cnt >> 1);
         const int wi0 = min(max(kk - W0, 1), L::MW - 1);
-        const float upper = col[(L::XW + wi0) * PW], lower = col[(L::XW + wi0 - 1) * PW];
+        const float upper = col[(V::XW + wi0) * PW], lower = col[(V::XW + wi0 - 1) * PW];
         const float median = (cnt & 1) ? upper : 0.5f * (lower + upper);       // qsort.go:68-82
 
         // ---- moments of the survivors: fixed part + tables + the partial groups at a and b ----
@@ -710,10 +730,10 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
                     // coarse start: every 8th rank of the columns
                     int t_lo = 0, t_hi = 0;
                     static_range<0, KL / 8>([&](auto G) NL_INL {
-                        t_lo += (col[(L::XL + 8 * decltype(G)::value + 7) * PW] < wi.Lp) ? 1 : 0;
+                        t_lo += (col[(V::XL + 8 * decltype(G)::value + 7) * PW] < wi.Lp) ? 1 : 0;
                     });
                     static_range<0, KH / 8>([&](auto G) NL_INL {
-                        t_hi += (col[(L::XH + 8 * decltype(G)::value) * PW] > wi.Hm) ? 1 : 0;
+                        t_hi += (col[(V::XH + 8 * decltype(G)::value) * PW] > wi.Hm) ? 1 : 0;
                     });
                     jl = max(jl, 8 * t_lo);
                     jh = min(jh, KH - 8 * t_hi);
@@ -723,8 +743,8 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
                 bool more = inner;
                 while (__any(more)) {
                     const int jlc = min(jl, KL - 8), jhc = max(jh, 8);
-                    const float *pl = col + (L::XL + jlc) * PW;
-                    const float *ph = col + (L::XH + jhc - 8) * PW;
+                    const float *pl = col + (V::XL + jlc) * PW;
+                    const float *ph = col + (V::XH + jhc - 8) * PW;
                     int up = 0, dn = 0;
                     static_range<0, 8>([&](auto I) NL_INL {
                         up += (pl[decltype(I)::value * PW] < wi.Lp) ? 1 : 0;
@@ -742,8 +762,8 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
                 const int gj = jlc >> 2, gh = jhc >> 2;
                 float dp = 0.0f, qp = 0.0f;
                 {
-                    const float *pl = col + (L::XL + jlc) * PW;
-                    const float *ph = col + (L::XH + jhc - 4) * PW;
+                    const float *pl = col + (V::XL + jlc) * PW;
+                    const float *ph = col + (V::XH + jhc - 4) * PW;
                     const int nlp = 4 - (jlc & 3), nhp = jhc & 3;
                     static_range<0, 4>([&](auto I) NL_INL {
                         constexpr int i = decltype(I)::value;
@@ -753,8 +773,8 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
                         dp += f; qp = __builtin_fmaf(f, f, qp);
                     });
                 }
-                const float tl1 = col[(L::SL1 + gj + 1) * PW], tl2 = col[(L::SL2 + gj + 1) * PW];
-                const float th1 = col[(L::SH1 + gh) * PW], th2 = col[(L::SH2 + gh) * PW];
+                const float tl1 = tab[(V::SL1 + gj + 1) * PW], tl2 = tab[(V::SL2 + gj + 1) * PW];
+                const float th1 = tab[(V::SH1 + gh) * PW], th2 = tab[(V::SH2 + gh) * PW];
                 const float n_lo = (float)(jl - a), n_hi = (float)(bl - jh);
                 const float eL = wi.Lp - c, eH = wi.Hm - c;               // max(x, Lp) - c of a clamped sample
                 const float dcl = n_lo * eL + n_hi * eH;
@@ -877,23 +897,134 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
 #endif
     if constexpr (L::PACK) {
         if (lane == 0) {                                   // (the one wave of the rounds phase)
-            unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+            unsigned long long *slot = p.partial + 2 * (size_t)(blk % kClipSlots);
             if (c_lo_total) atomicAdd(slot + 0, (unsigned long long)c_lo_total);
             if (c_hi_total) atomicAdd(slot + 1, (unsigned long long)c_hi_total);
         }
     } else {
-        __shared__ int s_lo[4], s_hi[4];
         if (lane == 0) { s_lo[threadIdx.x >> 6] = c_lo_total; s_hi[threadIdx.x >> 6] = c_hi_total; }
         __syncthreads();
         if (threadIdx.x == 0) {
             int t_lo = 0, t_hi = 0;
             for (int w = 0; w < L::BLOCK / 64; w++) { t_lo += s_lo[w]; t_hi += s_hi[w]; }
-            unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+            unsigned long long *slot = p.partial + 2 * (size_t)(blk % kClipSlots);
             if (t_lo) atomicAdd(slot + 0, (unsigned long long)t_lo);
             if (t_hi) atomicAdd(slot + 1, (unsigned long long)t_hi);
         }
     }
+    };   // ---- end of the rounds phase ----
+
+    if constexpr (PHASE == 3) {
+        // ---- persistent workgroups: block k of this workgroup is blockIdx.x + k * gridDim.x.  No barrier: wave (k mod 4)
+        // runs the rounds of block k AFTER it has sorted its share of block k + 1 -- by then the other waves' rows of
+        // block k have long been there, and its own lag (one rounds phase in four blocks, every wave in turn) never makes
+        // another wave wait: nobody idles, nobody retires.  Two column buffers (a block's rows are overwritten two blocks
+        // later, when its rounds are long over); the flags below only make that certain.
+        if (threadIdx.x < 2) { s_done[threadIdx.x] = 0u; s_freed[threadIdx.x] = 0u; }
+        __syncthreads();
+        // All workgroups start together and every block takes the same time: without a stagger the three waves of a SIMD
+        // would gather at the same time and sort at the same time for the whole launch -- nothing to hide the loads behind.
+        // The k-th third of the grid (the dispatcher fills the CUs once per third) starts a third of a block's time later.
+        {
+            // (HW_ID[3:0]: the wave's slot on its SIMD)
+            const int third = (int)((__builtin_amdgcn_s_getreg(63492) & 15u) % 3u);
+            for (int i = 0; i < NL_MLZ_STAGGER * third; i++) __builtin_amdgcn_s_sleep(127);
+        }
+        // (a real call: inlined, the rounds phase's loop invariants -- lane masks, addresses, constants -- are kept in registers
+        // across the sorting phase of every trip, which has none to spare: 55 spilled registers instead of 4, their reloads
+        // on the waves' critical path)
+        auto rounds_call = [&](const int64_t rblk, float *const rcol, float *const rtab) NL_INL {
+            rounds_phase(rblk, rcol, rtab);
+        };
+        const int wave = (int)(threadIdx.x >> 6);
+        const int64_t nblk = (p.npix + PW - 1) / PW;
+        float *const tabbase = lds + 2 * V::ROWS * PW;
+        for (int k = 0;; k++) {
+            const int64_t blk = (int64_t)blockIdx.x + (int64_t)k * (int64_t)gridDim.x;
+            const bool has = blk < nblk;                   // (the same for every wave of the workgroup)
+#if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
+            const unsigned long long tt0 = __builtin_readcyclecounter();
+#endif
+            if (has) {
+                float *const buf = lds + (k & 1) * (V::ROWS * PW);
+                sorting_phase(blk, buf, [&]() NL_INL {
+#if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
+                    const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
+                    if (k >= 2) mlz_spin_until(&s_freed[k & 1], (unsigned)(k >> 1));      // rounds of block k - 2 are over
+#if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
+                    if (threadIdx.x == 0) NL_STAT(3, __builtin_readcyclecounter() - ts0);
+#endif
+                });
+                lds_settle();
+                if (lane == 0) __hip_atomic_fetch_add(&s_done[k & 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
+                if (threadIdx.x == 0) { NL_STAT(5, __builtin_readcyclecounter() - tt0); NL_STAT(4, 1); }
+#endif
+            }
+            const int j = k - 1;
+            if (j >= 0 && (j & 3) == wave) {
+#if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
+                const unsigned long long ts1 = __builtin_readcyclecounter();
+#endif
+                mlz_spin_until(&s_done[j & 1], 4u * (unsigned)((j >> 1) + 1));             // every wave's rows of block j
+                if (j >= 1) mlz_spin_until(&s_freed[(j - 1) & 1], (unsigned)(((j - 1) >> 1) + 1));      // the table area is free
+#if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
+                if (lane == 0) NL_STAT(2, __builtin_readcyclecounter() - ts1);
+#endif
+                rounds_call(blk - (int64_t)gridDim.x, lds + (j & 1) * (V::ROWS * PW), tabbase);
+                lds_settle();
+                if (lane == 0) __hip_atomic_fetch_add(&s_freed[j & 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (!has) break;
+        }
+        return;
+    } else {
+    if constexpr (PHASE == 2) {
+        // ---- the columns the sorting kernel left: rows of 64 pixels, back to their places in LDS ----
+        const float *src = q.cols + (size_t)blockIdx.x * (size_t)(SP::N * PW) + lane;
+        static_range<0, SP::N>([&](auto G) NL_INL {
+            constexpr int g = decltype(G)::value;
+            lds[SP::row(g) * PW + lane] = src[g * PW];
+        });
+        lds_settle();
+    } else {
+        sorting_phase((int64_t)blockIdx.x, lds, []() NL_INL {});
+    }
+    if constexpr (PHASE == 1) {
+        // the columns, the window and the scalars of the workgroup's 64 pixels: 256-byte rows, every wave its share
+        __syncthreads();
+        float *dst = q.cols + (size_t)blockIdx.x * (size_t)(SP::N * PW) + lane;
+        static_range<0, (SP::N + 3) / 4>([&](auto G) NL_INL {
+            const int g = 4 * decltype(G)::value + (int)(threadIdx.x >> 6);
+            if (g < SP::N) dst[g * PW] = lds[SP::row_rt(g) * PW + lane];
+        });
+        return;
+    } else if constexpr (PHASE == 2) {
+        // (one wave: nothing to meet)
+    } else if constexpr (L::PACK) {
+        __syncthreads();
+#ifdef NL_MLZ_EXP_SORTONLY
+        if (p.npix > 0) return;                            // (timing experiment: the sorting phase alone)
+#endif
+        if ((int)(threadIdx.x >> 6) != (int)(blockIdx.x % (L::BLOCK / 64))) return;
+#ifdef NL_MLZ_EXP_PRIO
+        __builtin_amdgcn_s_setprio(NL_MLZ_EXP_PRIO);
+#endif
+#ifdef NL_MLZ_EXP_SLEEP
+        if (p.npix > 0) {                                  // (timing experiment: the rounds wave only holds its slot)
+            for (int i = 0; i < NL_MLZ_EXP_SLEEP; i++) __builtin_amdgcn_s_sleep(127);
+            return;
+        }
+#endif
+        // (s_setprio 3 for this wave -- it holds the workgroup's LDS -- measured 0.5 % slower, two interleaved runs)
+    } else {
+        lds_settle();
+    }
+    rounds_phase((int64_t)blockIdx.x, lds, lds);
+    }
 }
+
 
 // launches the kernel of frame-count class `ntop` if this translation unit instantiates it
 template <int LPP, int... NTOPS>
@@ -914,6 +1045,15 @@ static bool launch_mlz_classes(int ntop, bool winsor, const StackArgs &args, con
                 // workgroup's four wave slots idle while its fourth wave runs the rounds), then one wave per 64 pixels
                 hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, false, NTOP, 1>), grid, dim3(L::BLOCK), 0, stream, args, f);
                 hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, false, NTOP, 2>), grid, dim3(64), 0, stream, args, f);
+            } else if (f.persistent) {
+                // persistent workgroups, three per CU (168 registers: three waves per SIMD), each looping over blocks of 64 pixels
+                static const int cus = [] {
+                    int dev = 0, n = 0;
+                    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+                    return n;
+                }();
+                const unsigned wgs = (unsigned)(3 * cus);
+                hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, false, NTOP, 3>), dim3(grid.x < wgs ? grid.x : wgs), dim3(L::BLOCK), 0, stream, args, f);
             } else {
                 hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, false, NTOP>), grid, dim3(L::BLOCK), 0, stream, args, f);
             }

@@ -100,6 +100,9 @@ struct FastArgs {
     // nullptr: one kernel does both.
     float *cols = nullptr;
     long long cols_stride = 0;
+    // The same class as PERSISTENT workgroups (three per CU, each looping over blocks of 64 pixels; the rounds of a block run in one
+    // of its waves while the others are sorting the next block -- stack_fast_mlz_impl.hpp, PHASE 3).  0: one workgroup per block.
+    int persistent = 0;
 };
 
 // sets what nl_last_error() returns on this thread (nlstack_api.hip)

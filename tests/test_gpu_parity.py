@@ -764,8 +764,9 @@ def test_developer_switches_do_not_change_results(nl, oracle, mode, n, weighted)
 @pytest.mark.parametrize("n,weighted,height", [(512, False, 12), (500, False, 9), (512, True, 6)])
 def test_split_lds_column_pass_gives_the_bits_of_the_one_kernel_pass(nl, oracle, n, weighted, height):
     # developer switch 1024: the selected LDS-column kernel (497 ... 512 frames, plain sigma) as a sorting kernel plus a
-    # rounds kernel over columns kept in device memory (FastArgs::cols) -- same code for the rounds, so the same bits,
-    # counters and hand-over lists; a ragged last workgroup (height * width not a multiple of 64) included
+    # rounds kernel over columns kept in device memory (FastArgs::cols); 2048: as persistent workgroups that loop over
+    # blocks of 64 pixels without a barrier -- same code for the rounds, so the same bits, counters and hand-over lists;
+    # a ragged last workgroup (height * width not a multiple of 64) included
     width = 4096 if height != 9 else 1000
     with nl.StackHandle(n, width, 4096, row0=0, rows=height) as st:
         st.fill_synthetic(9)
@@ -773,7 +774,7 @@ def test_split_lds_column_pass_gives_the_bits_of_the_one_kernel_pass(nl, oracle,
             st.set_weights(np.random.default_rng(n).uniform(0.2, 1.0, n).astype(np.float32))
         ref = None
         b0 = None
-        for flags in (0, 1024, 1024 | 1, 0):
+        for flags in (0, 1024, 1024 | 1, 2048, 2048 | 1, 0):
             st.set_dev_flags(flags)
             got, cl, ch = st.run(2, 3.0, 2.5)
             got = got[:height * width]

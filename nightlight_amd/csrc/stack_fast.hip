@@ -519,6 +519,8 @@ static hipError_t launch_pair(const StackArgs &args, const FastArgs &fargs, unsi
             f.pass_budget = fargs.cas_pass[0];
             f.round_cap = fargs.cas_cap[0];
         }
+        // (workgroups of 64 or 128 threads instead of 256 -- no wave waits for its workgroup's slowest at the barriers of the
+        // hand-over lists -- measured the same within the noise at 32 and 128 frames, round 4)
         if (args.n_frames == NS) {
             *name = sigma_kernel_name<NS, true, WINSOR, true>();
             hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, true, WINSOR, true>), dim3(tile_blocks), dim3(256), 0,

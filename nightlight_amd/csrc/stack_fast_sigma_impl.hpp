@@ -642,8 +642,8 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
     if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = c_lo_total; s_hi[threadIdx.x >> 6] = c_hi_total; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int t_lo = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3];
-        const int t_hi = s_hi[0] + s_hi[1] + s_hi[2] + s_hi[3];
+        int t_lo = 0, t_hi = 0;
+        for (unsigned w = 0; w < (blockDim.x >> 6); w++) { t_lo += s_lo[w]; t_hi += s_hi[w]; }
         unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
         if constexpr (!ZONAL) slot = clip_slot(p);
         if (t_lo) atomicAdd(slot + 0, (unsigned long long)t_lo);

@@ -38,16 +38,20 @@ hipError_t launch_stack_sigma_mlz(const StackArgs &args, const FastArgs &fargs, 
     f.in_capacity = 0;
     const int ntop = (args.n_frames + 15) / 16 * 16;
     const int lpp = args.n_frames <= 256 ? 2 : 4;
-    // kernel names as rocprofv3 prints them (template arguments: LPP, WINSOR, NTOP)
+    // kernel names as rocprofv3 prints them (template arguments: LPP, WINSOR, NTOP, PHASE -- 0: the whole pass in one kernel;
+    // the experimental passes of the selected class report their sorting kernel, 1, or the persistent kernel, 3)
     static const std::string *names = [] {
-        static std::string t[2][33];
-        for (int w = 0; w < 2; w++)
-            for (int c = 9; c <= 32; c++)
-                t[w][c] = "stack_sigma_mlz_kernel<" + std::to_string(c <= 16 ? 2 : 4) + (w ? ", true, " : ", false, ") +
-                          std::to_string(16 * c) + ">";
-        return &t[0][0];
+        static std::string t[3][2][33];
+        for (int ph = 0; ph < 3; ph++)
+            for (int w = 0; w < 2; w++)
+                for (int c = 9; c <= 32; c++)
+                    t[ph][w][c] = "stack_sigma_mlz_kernel<" + std::to_string(c <= 16 ? 2 : 4) + (w ? ", true, " : ", false, ") +
+                                  std::to_string(16 * c) + (ph == 0 ? ", 0>" : (ph == 1 ? ", 1>" : ", 3>"));
+        return &t[0][0][0];
     }();
-    *name = names[(winsor ? 33 : 0) + ntop / 16].c_str();
+    const bool selected = !winsor && mlz_split_rows(NL_ST_SIGMA, args.n_frames) != 0;
+    const int ph = !selected ? 0 : (fargs.cols ? 1 : (fargs.persistent ? 2 : 0));
+    *name = names[(ph * 2 + (winsor ? 1 : 0)) * 33 + ntop / 16].c_str();
     (void)lpp;
     const bool ok = launch_mlz_part_a(ntop, winsor, args, f, stream) || launch_mlz_part_b(ntop, winsor, args, f, stream) ||
                     launch_mlz_part_c(ntop, winsor, args, f, stream) || launch_mlz_part_d(ntop, winsor, args, f, stream);

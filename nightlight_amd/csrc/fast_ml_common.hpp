@@ -274,6 +274,80 @@ __device__ __forceinline__ int ml_gather_raw(const float *frames, int64_t stride
     return quad_sum<LPP>(NS - nan_cnt - spad);
 }
 
+// The gather of a frame-count class that fills its lanes (NLOAD == NS, KPAD0 >= NS / 2) together with the in-lane sort, in
+// two halves: all NS loads are issued, but the lane only waits for the first NS / 2 of them (loads return in order), tests
+// and sorts those -- a network of NS / 2 positions -- while the second half arrives, sorts that, and merges the two runs
+// (second run taken backwards: a bitonic sequence, FusedBitonic<NS, 0>).  821 + 821 + 626 operations instead of the 2 184 of
+// the 128-network, 4 % more -- for not standing idle through a whole gather: the network's first layer already touches every
+// position, and the test for NaN samples in front of it needs every load anyway.  MEASURED SLOWER (round 4, sigma 512 x 4096^2:
+// 10.98 against 10.13 ms, 14 instead of 4 spilled registers): with three waves per SIMD the gather of one wave already hides
+// behind the networks of the other two.  Only A/B builds (NL_MLZ_HALVES) use it.
+template <int LPP, int NS, int KPAD0, int NLOAD>
+__device__ __forceinline__ int ml_gather_sort_halves(const float *frames, int64_t stride, int N, bool on, int64_t pix,
+                                                     int role, float (&v)[NS])
+{
+    static_assert(NLOAD == NS && KPAD0 >= NS / 2 && KPAD0 <= NS, "a class that fills its lanes");
+    constexpr int H = NS / 2;
+    int nan_cnt = 0, spad = 0;
+    int frame_bytes = (int)(stride * (int64_t)sizeof(float));
+    asm volatile("" : "+s"(frame_bytes));                      // (see ml_gather_raw)
+    const int voff = (int)((unsigned)(on ? pix : 0) * 4u) + role * frame_bytes;
+    static_chunks<0, NS, 4>([&](auto K) NL_INL {
+        constexpr int k = decltype(K)::value;
+        const int avail = min(max(N - k * LPP, 0), LPP);
+        const char *gb = reinterpret_cast<const char *>(frames) + (int64_t)(k * LPP) * frame_bytes;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(gb), 0, avail * frame_bytes, 0x00020000);
+        v[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
+    });
+    auto nan_fix = [&](auto B, auto E) NL_INL {
+        static_chunks<decltype(B)::value, decltype(E)::value, 8>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            nan_cnt = opaque(nan_cnt - ((0x7f800000 - (__float_as_int(v[k]) & 0x7fffffff)) >> 31));
+            asm volatile("v_min_f32 %0, %0, %1" : "+v"(v[k]) : "v"(__builtin_inff()));   // NaN -> +Inf in place
+        });
+    };
+    // ---- first half: every position holds a frame ----
+    {
+        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+        static_chunks<0, H / 4, 8>([&](auto K) NL_INL {
+            constexpr int k = 4 * decltype(K)::value;
+            t0 += v[k]; t1 += v[k + 1]; t2 += v[k + 2]; t3 += v[k + 3];
+        });
+        const float total = (t0 + t1) + (t2 + t3);
+        if (__any(!(__builtin_fabsf(total) < __builtin_inff()))) nan_fix(std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
+        float a[H];
+        static_range<0, H>([&](auto K) NL_INL { a[decltype(K)::value] = v[decltype(K)::value]; });
+        sort_network<H>(a);
+        static_range<0, H>([&](auto K) NL_INL { v[decltype(K)::value] = a[decltype(K)::value]; });
+    }
+    // ---- second half: positions from KPAD0 on may lie beyond the last frame (-> +Inf, counted, out of the sum) ----
+    {
+        int lastp = opaque(N - 1) - role;
+        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f, tp = 0.0f;
+        static_range<KPAD0, NS>([&](auto K) NL_INL {
+            constexpr int k = decltype(K)::value;
+            const int pad = (lastp - k * LPP) >> 31;                       // all ones: no frame
+            tp += __int_as_float(__float_as_int(v[k]) & ~pad);
+            v[k] = __int_as_float((__float_as_int(v[k]) & ~pad) | (0x7f800000 & pad));
+            spad -= pad;
+        });
+        static_chunks<H / 4, KPAD0 / 4, 8>([&](auto K) NL_INL {
+            constexpr int k = 4 * decltype(K)::value;
+            t0 += v[k]; t1 += v[k + 1]; t2 += v[k + 2]; t3 += v[k + 3];
+        });
+        static_range<KPAD0 / 4 * 4, KPAD0>([&](auto K) NL_INL { t0 += v[decltype(K)::value]; });
+        const float total = ((t0 + tp) + t1) + (t2 + t3);
+        if (__any(!(__builtin_fabsf(total) < __builtin_inff()))) nan_fix(std::integral_constant<int, H>{}, std::integral_constant<int, NS>{});
+        float b[H];
+        static_range<0, H>([&](auto K) NL_INL { b[decltype(K)::value] = v[H + decltype(K)::value]; });
+        sort_network<H>(b);
+        static_range<0, H>([&](auto K) NL_INL { v[H + decltype(K)::value] = b[H - 1 - decltype(K)::value]; });   // backwards
+    }
+    run_network<FusedBitonic<NS, 0>, NS>(v);
+    return quad_sum<LPP>(NS - nan_cnt - spad);
+}
+
 template <int LPP, int NS, bool ENDS_ONLY, int KEEP = 16, int CH = 32, int NSL = NS, int KPAD0 = NS / 2, int NLOAD = NS>
 __device__ __forceinline__ int ml_gather_sorted(const float *frames, int64_t stride, int N, bool on, int64_t pix,
                                                 int role, float (&v)[NS])

@@ -745,7 +745,10 @@ static void set_split_cols(nl_stack *h, int mode, int n_frames, nl::FastArgs &f)
     // (the same class as persistent workgroups -- three per CU, no barrier, the rounds of a block behind the sorting of the
     // next: also built, also slower; NL_MLZ_PERSIST=1 / developer switch 2048)
     static const bool persist = [] { const char *e = getenv("NL_MLZ_PERSIST"); return e && e[0] == '1'; }();
-    if (rows != 0 && (persist || (h->dev_flags & 2048u)) && !(h->dev_flags & 1024u)) f.persistent = 1;
+    if (rows != 0 && (persist || (h->dev_flags & 2048u)) && !(h->dev_flags & 1024u) && f.fb_count) {
+        f.persistent = 1;
+        f.ticket = f.fb_count + 3;                     // (fourth word of the pass's list counters: zeroed with them)
+    }
     if (rows == 0 || !(on || (h->dev_flags & 1024u))) return;
     if (!h->d_cols && !h->cols_tried) {
         h->cols_tried = true;

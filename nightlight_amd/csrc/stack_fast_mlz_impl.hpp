@@ -31,12 +31,12 @@
 namespace nl {
 
 #ifdef NL_ROUND_STATS
-__device__ unsigned long long nl_dbg_rounds_mlz[8];          // hand-over causes: [0] missing samples, [1] c2 >= 8, [2] d2 >= 8,
+__device__ unsigned long long nl_dbg_rounds_mlz[16];          // hand-over causes: [0] missing samples, [1] c2 >= 8, [2] d2 >= 8,
 extern "C" int nl_debug_round_stats_mlz(unsigned long long *out, int reset)     // [3] low zone, [4] high zone, [5] shape -> exact
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nl_dbg_rounds_mlz), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nl_dbg_rounds_mlz), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[8] = {};
+        unsigned long long z[16] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(nl_dbg_rounds_mlz), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;
@@ -398,6 +398,7 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     // (PHASE 3: two column buffers and one table area)
     __shared__ float lds[(PHASE == 3 ? 2 * V::ROWS + V::TROWS : L::ROWS) * PW];
     __shared__ unsigned s_done[2], s_freed[2];             // PHASE 3: waves that wrote / rounds that finished, per buffer
+    __shared__ unsigned s_blk[4], s_seq;                   // PHASE 3: the workgroup's block of trip k (slot k & 3), trips published
     __shared__ int s_lo[4], s_hi[4];                       // (kernels whose rounds run in every wave: their clip counts)
     if constexpr (PHASE != 2) fused_prologue_dominant(p);
 
@@ -419,6 +420,9 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     const int role = tid % LPP;
     float *col = colbase + tid / LPP;                      // element r of this pixel: col[r * PW]
     const int64_t pix = blk * PW + tid / LPP;
+    // (PHASE 3: the wait for the buffer -- over long before -- stands HERE, not in front of the first store: a loop in the
+    // middle of the sorting phase cuts its one basic block in two and cost 14 more spilled registers)
+    if constexpr (L::SELECT) before_store();
     const bool on = pix < p.npix;
     int N = p.n_frames;
     // (PHASE 3 calls this in a loop: re-read through an opaque register, or the per-frame scalar selects that depend on the
@@ -429,9 +433,24 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     // (columns of the plain sigma kernel, median window); the winsorized columns are longer, and the
     // columns of a shorter stack sit inside the lanes: full merge
     int n;
+#if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
+    const unsigned long long sp0 = __builtin_readcyclecounter();
+    unsigned long long sp1 = sp0, sp2 = sp0, sp3 = sp0;
+#endif
     if constexpr (L::SELECT) {
+        // (the lanes' runs are not merged: select_ends / select_window)
+#ifdef NL_MLZ_HALVES             // (A/B builds: sort the first 64 positions while the other 64 loads are in flight -- 8 % slower)
+        n = ml_gather_sort_halves<LPP, NS, (NTOP - 16) / LPP, NTOP / LPP>(p.frames, p.stride, N, on, pix, role, v);
+#else
         n = ml_gather_raw<LPP, NS, (NTOP - 16) / LPP, NTOP / LPP>(p.frames, p.stride, N, on, pix, role, v);
-        sort_network<NS>(v);                               // the lanes' runs are not merged: select_ends / select_window
+#if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
+        __builtin_amdgcn_sched_barrier(0); sp1 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#endif
+        sort_network<NS>(v);
+#if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
+        __builtin_amdgcn_sched_barrier(0); sp2 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#endif
+#endif
     } else {
         n = ml_gather_sorted<LPP, NS, L::FULL && !WINSOR, 32, 32, L::NSL, (NTOP - 16) / LPP, NTOP / LPP>(p.frames, p.stride, N, on, pix,
                                                                                                               role, v);
@@ -452,8 +471,10 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         // shift: the middle of the first lane's run (any value near the bulk works)
         c_sel = bcast_f(std::integral_constant<int, 0>{}, v[NS / 2]);
         float t_lo, t_hi;                                  // innermost values of the low / high column
-        before_store();
         select_ends<L, LPP, NS, V>(v, role, col, t_lo, t_hi);
+#if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
+        __builtin_amdgcn_sched_barrier(0); sp3 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#endif
         // moments of every sample of the pixel, the ends of the runs clamped to [t_lo, t_hi]: the KL + KH samples
         // of the columns count as t_lo / t_hi (a missing sample, +Inf, as t_hi) and are taken off again
         {
@@ -541,6 +562,12 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         col[(V::PS + 6) * PW] = x_in_lo;
         col[(V::PS + 7) * PW] = x_in_hi;
     }
+#if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
+    if (threadIdx.x == 0) {
+        const unsigned long long sp4 = __builtin_readcyclecounter();
+        NL_STAT(8, sp1 - sp0); NL_STAT(9, sp2 - sp1); NL_STAT(10, sp3 - sp2); NL_STAT(11, sp4 - sp3); NL_STAT(12, 1);
+    }
+#endif
     };   // ---- end of the sorting phase ----
 
     // ---- rounds phase of block `blk`: columns at `colbase`, tables at `tabbase` ----
@@ -920,7 +947,10 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         // block k have long been there, and its own lag (one rounds phase in four blocks, every wave in turn) never makes
         // another wave wait: nobody idles, nobody retires.  Two column buffers (a block's rows are overwritten two blocks
         // later, when its rounds are long over); the flags below only make that certain.
+        // Blocks are handed out in order through a device counter (FastArgs::ticket): with a fixed stride per workgroup the
+        // workgroups drift apart over hundreds of trips and the 512 frames are read at ever more scattered places.
         if (threadIdx.x < 2) { s_done[threadIdx.x] = 0u; s_freed[threadIdx.x] = 0u; }
+        if (threadIdx.x == 0) { s_blk[0] = atomicAdd(q.ticket, 1u); s_seq = 1u; }
         __syncthreads();
         // All workgroups start together and every block takes the same time: without a stagger the three waves of a SIMD
         // would gather at the same time and sort at the same time for the whole launch -- nothing to hide the loads behind.
@@ -939,9 +969,13 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
         const int wave = (int)(threadIdx.x >> 6);
         const int64_t nblk = (p.npix + PW - 1) / PW;
         float *const tabbase = lds + 2 * V::ROWS * PW;
+        int64_t prev_blk = 0;
         for (int k = 0;; k++) {
-            const int64_t blk = (int64_t)blockIdx.x + (int64_t)k * (int64_t)gridDim.x;
+            mlz_spin_until(&s_seq, (unsigned)k + 1u);      // (wave 0 published this trip's block while sorting the last one)
+            const int64_t blk = (int64_t)__builtin_amdgcn_readfirstlane((int)s_blk[k & 3]);
             const bool has = blk < nblk;                   // (the same for every wave of the workgroup)
+            unsigned next_ticket = 0u;
+            if (has && threadIdx.x == 0) next_ticket = atomicAdd(q.ticket, 1u);     // (returns behind the gather's loads)
 #if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
             const unsigned long long tt0 = __builtin_readcyclecounter();
 #endif
@@ -958,6 +992,10 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
                 });
                 lds_settle();
                 if (lane == 0) __hip_atomic_fetch_add(&s_done[k & 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (threadIdx.x == 0) {
+                    s_blk[(k + 1) & 3] = next_ticket;
+                    __hip_atomic_store(&s_seq, (unsigned)k + 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
 #if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
                 if (threadIdx.x == 0) { NL_STAT(5, __builtin_readcyclecounter() - tt0); NL_STAT(4, 1); }
 #endif
@@ -972,11 +1010,12 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
 #if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
                 if (lane == 0) NL_STAT(2, __builtin_readcyclecounter() - ts1);
 #endif
-                rounds_call(blk - (int64_t)gridDim.x, lds + (j & 1) * (V::ROWS * PW), tabbase);
+                rounds_call(prev_blk, lds + (j & 1) * (V::ROWS * PW), tabbase);
                 lds_settle();
                 if (lane == 0) __hip_atomic_fetch_add(&s_freed[j & 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (!has) break;
+            prev_blk = blk;
         }
         return;
     } else {
@@ -1052,7 +1091,8 @@ static bool launch_mlz_classes(int ntop, bool winsor, const StackArgs &args, con
                     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
                     return n;
                 }();
-                const unsigned wgs = (unsigned)(3 * cus);
+                static const int per_cu = [] { const char *e = getenv("NL_MLZ_WGS_PER_CU"); const int v = e ? atoi(e) : 3; return v >= 1 && v <= 8 ? v : 3; }();      // (experiments)
+                const unsigned wgs = (unsigned)(per_cu * cus);
                 hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, false, NTOP, 3>), dim3(grid.x < wgs ? grid.x : wgs), dim3(L::BLOCK), 0, stream, args, f);
             } else {
                 hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, false, NTOP>), grid, dim3(L::BLOCK), 0, stream, args, f);

@@ -103,6 +103,7 @@ struct FastArgs {
     // The same class as PERSISTENT workgroups (three per CU, each looping over blocks of 64 pixels; the rounds of a block run in one
     // of its waves while the others are sorting the next block -- stack_fast_mlz_impl.hpp, PHASE 3).  0: one workgroup per block.
     int persistent = 0;
+    unsigned *ticket = nullptr;   // persistent workgroups: the next block to hand out (zero at the start of the pass)
 };
 
 // sets what nl_last_error() returns on this thread (nlstack_api.hip)

@@ -407,11 +407,13 @@ struct WinsorInterval {
     float w_lo, w_hi;              // the reference's current std lies in here
     float Lm, Lp, Hm, Hp;          // effective clamp: low bound in [Lm, Lp], high bound in [Hm, Hp]
     float hull_lo, hull_hi;        // values the reference may have left the loop with
-    int guard;
+    int guard, guard_max;
     bool ch_sure, ch_none;         // "changed > 0" certain / "changed == 0" certain, this round
 
-    __device__ __forceinline__ void start(float s_min, float s_max)
+    // max_rounds: a pixel that is still inside the loop after that many rounds goes to the exact replay
+    __device__ __forceinline__ void start(float s_min, float s_max, int max_rounds = 100)
     {
+        guard_max = max_rounds;
         w_lo = s_min; w_hi = s_max;
         Lm = Lp = -__builtin_inff();           // running max of the low bounds
         Hm = Hp = __builtin_inff();            // running min of the high bounds
@@ -457,7 +459,7 @@ struct WinsorInterval {
             const bool may_stop = !ch_sure || !go_sure;
             const bool must_stop = ch_none || stop_sure;          // implies may_stop
             if (may_stop) { hull_lo = fminf(hull_lo, w_lo); hull_hi = fmaxf(hull_hi, w_hi); }
-            if (!shape_ok || !(w_hi < 3.0e38f) || ++guard > 100) { bail = true; inner = false; }
+            if (!shape_ok || !(w_hi < 3.0e38f) || ++guard > guard_max) { bail = true; inner = false; }
             else if (must_stop) inner = false;
         }
     }

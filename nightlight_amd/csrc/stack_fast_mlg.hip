@@ -281,7 +281,7 @@ void stack_sigma_mlg_kernel(StackArgs p, FastArgs q)
                 // ---- winsorized stddev (stack.go:646-672) as an interval, WinsorInterval in fast_common.hpp ----
                 // ranks [a, jl) sit on the low clamp, [jh, b) on the high clamp; both only tighten inside one loop
                 WinsorInterval wi;
-                wi.start(s_min, s_max);
+                wi.start(s_min, s_max, q.gen_round_cap > 0 ? q.gen_round_cap : 100);      // (see FastArgs::gen_round_cap)
                 bool inner = active && !bail;
                 int jl = a, jh = b;
                 bool first = true;

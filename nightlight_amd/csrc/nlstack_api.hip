@@ -1126,7 +1126,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
             f.gen_capacity = (unsigned)len;
             f.gen_hint = h->gen_hint ? (unsigned)((double)(h->gen_hint - 1u) * share * 1.25) + 1u : 0u;
             if (!weighted) set_split_cols(h, mode, ak.n_frames, f);     // (chunks run one after the other on the pass's stream: one buffer)
-            if (mode == NL_ST_WINSOR_SIGMA) f.gen_round_cap = ak.n_frames >= 48 ? 24 : 40;
+            if (mode == NL_ST_WINSOR_SIGMA) f.gen_round_cap = ak.n_frames >= 48 ? 24 : (ak.n_frames > 20 ? 32 : 40);
             nl::StackArgs e = ak;
             e.list = f.fb_list;
             e.list_count = cc;
@@ -1204,11 +1204,11 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
         f.in_count = nullptr;
         f.in_capacity = 0;
         if (!weighted) set_split_cols(h, mode, a.n_frames, f);
-        // winsorized generic passes: a wave runs for its slowest pixel, and the few pixels whose winsorization loops take
-        // dozens of rounds are cheaper in the replay (NL_GEN_ROUND_CAP: rounds per clipping pass; 100 = the limit of every kernel)
+        // winsorized generic passes and the stages of the cascade behind the dominant kernel: a wave runs for its slowest pixel,
+        // and the few pixels whose winsorization loops take dozens of rounds are cheaper in the replay (NL_GEN_ROUND_CAP: rounds per clipping pass; 100 = the limit of every kernel)
         if (mode == NL_ST_WINSOR_SIGMA) {
             static const int cap_env = [] { const char *e = getenv("NL_GEN_ROUND_CAP"); return e ? atoi(e) : 0; }();
-            f.gen_round_cap = cap_env > 0 ? cap_env : (a.n_frames >= 48 ? 24 : 40);
+            f.gen_round_cap = cap_env > 0 ? cap_env : (a.n_frames >= 48 ? 24 : (a.n_frames > 20 ? 32 : 40));
         }
         // winsorized clipping of 16 ... 128 frames: the winsorization cascade (stack_fast_sigma_impl.hpp) -- the dominant
         // kernel and a second stage stop at a budget of rounds per wave and hand their unfinished pixels on, a third

@@ -334,7 +334,8 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
                 const float xmax = pick<PZ, NS>(v, b - 1);
                 WinsorInterval wi;
                 // (generic pass: a wave runs for its slowest pixel -- the few pixels with very long loops are cheaper in the replay)
-                wi.start(s_min, s_max, (!ZONAL && q.gen_round_cap > 0) ? q.gen_round_cap : 100);
+                // (and the stages of the cascade behind the dominant kernel -- the last one has no budget of its own)
+                wi.start(s_min, s_max, ((!ZONAL || CONT) && q.gen_round_cap > 0) ? q.gen_round_cap : 100);
                 bool inner = active && !bail;
                 int rounds_left = (CASCADE && q.round_cap > 0) ? q.round_cap : 0x7fffffff;
                 while (__any(inner)) {

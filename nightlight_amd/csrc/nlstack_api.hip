@@ -1208,7 +1208,8 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
         // and the few pixels whose winsorization loops take dozens of rounds are cheaper in the replay (NL_GEN_ROUND_CAP: rounds per clipping pass; 100 = the limit of every kernel)
         if (mode == NL_ST_WINSOR_SIGMA) {
             static const int cap_env = [] { const char *e = getenv("NL_GEN_ROUND_CAP"); return e ? atoi(e) : 0; }();
-            f.gen_round_cap = cap_env > 0 ? cap_env : (a.n_frames >= 48 ? 24 : (a.n_frames > 20 ? 32 : 40));
+            // (measured per frame count on the bench stack; 12 / 13 frames -- the smallest stacks with a zonal kernel -- lose with 40)
+            f.gen_round_cap = cap_env > 0 ? cap_env : (a.n_frames >= 48 ? 24 : (a.n_frames > 20 ? 32 : ((a.n_frames == 12 || a.n_frames == 13) ? 60 : 40)));
         }
         // winsorized clipping of 16 ... 128 frames: the winsorization cascade (stack_fast_sigma_impl.hpp) -- the dominant
         // kernel and a second stage stop at a budget of rounds per wave and hand their unfinished pixels on, a third

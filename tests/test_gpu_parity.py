@@ -836,3 +836,51 @@ def test_destroyed_handles_park_their_buffers_for_the_next_one(nl, oracle):
         st.upload_frames(frames)
         third, cl2, ch2 = st.run(2, 2.5, 2.5)
     assert (cl2, ch2) == (cl0, ch0) and bits_equal(third, first)
+
+
+# ---- round 5: extreme magnitudes through the default dispatch -------------------------------------------------
+# The clipping passes of the fast kernels take their own moments with v_rcp_f32 / v_sqrt_f32 and widened margins
+# (fast_common.hpp, stack_fast_sigma_impl.hpp, stack_fast_mlz_impl.hpp); the margins decide which pixels are
+# handed to the bit-exact replay, i.e. whether the clip counters stay the reference's (stats.go:246-261,
+# stack.go:404-430).  Subnormal squares (x 1e-36), squares near the flush threshold (x 1e-30), overflowing
+# squares (x 1e30) and a constant third of the tile, with ordinary and degenerate kappas.
+_EXTREME_SCALES = {"sub36": 1e-36, "sub30": 1e-30, "big30": 1e30, "const3": None}
+_EXTREME_KAPPAS = [(3.0, 3.0), (0.01, 20.0), (-1.0, 2.5), (2.5, 0.0)]
+
+
+def _extreme_case(mode, n, scale, kidx):
+    width, height = 97, 5
+    seed = 7000 + 131 * mode + 7 * n + kidx
+    frames = make_frames(n, width, height, seed=seed, nan_frac=0.02 if n > 8 else 0.0,
+                         ties=bool((n + kidx) & 1))
+    s = _EXTREME_SCALES[scale]
+    if s is None:
+        frames[:, : width * height // 3] = np.float32(np.random.default_rng(seed).uniform(-5, 5))
+    else:
+        frames = (frames * np.float32(s)).astype(np.float32)
+    return width, height, frames
+
+
+@pytest.mark.parametrize("kidx", range(len(_EXTREME_KAPPAS)))
+@pytest.mark.parametrize("scale", sorted(_EXTREME_SCALES))
+@pytest.mark.parametrize("n", [8, 24, 32, 100, 128, 200, 512])
+@pytest.mark.parametrize("mode", [2, 3, 4])
+def test_extreme_magnitudes_default_dispatch(nl, oracle, mode, n, scale, kidx):
+    sl, sh = _EXTREME_KAPPAS[kidx]
+    width, height, frames = _extreme_case(mode, n, scale, kidx)
+    got, gc, want, wc = run_both(nl, oracle, mode, frames, width, height, None, sl, sh, exact=False)
+    assert gc == wc, "%s n=%d %s kappa %r: clip counters %r vs oracle %r" % (MODES[mode], n, scale, (sl, sh), gc, wc)
+    assert close_values(got, want), "%s n=%d %s kappa %r: %s" % (MODES[mode], n, scale, (sl, sh),
+                                                                   describe_mismatch(got, want))
+
+
+@pytest.mark.parametrize("scale", ["sub36", "big30"])
+@pytest.mark.parametrize("n", [32, 128, 200])
+@pytest.mark.parametrize("mode", [2, 3])
+def test_extreme_magnitudes_weighted_dispatch(nl, oracle, mode, n, scale):
+    # the weighted clip modes run the same pass body record-only (decision pass) in front of the bit-exact replay
+    width, height, frames = _extreme_case(mode, n, scale, 0)
+    w = np.random.default_rng(n).uniform(0.2, 1.0, n).astype(np.float32)
+    got, gc, want, wc = run_both(nl, oracle, mode, frames, width, height, w, 2.75, 2.75, exact=False)
+    assert gc == wc, (gc, wc)
+    assert same_values(got, want), describe_mismatch(got, want)

@@ -296,8 +296,30 @@ struct LinfitCascade {
     unsigned capacity;
 };
 constexpr int kLinfitStages = 4;
+constexpr int kLinfitCounters = 8;  // device list lengths of one pass (the bit-exact cascade uses the first kLinfitStages)
 int linfit_fast_supported(int mode, int n_frames, int64_t npix);
 int linfit_ml_supported(int mode, int n_frames, int64_t npix);
+
+// ---- stack_linfit_guard.hip (guarded stages in front of the bit-exact cascade, 17 ... 128 frames) ----
+// Three pixel lists with liveness masks (npix entries each) and kLinfitCounters list lengths, zeroed per pass:
+// two continuation lists ping-pong between the guarded stages, the third collects the pixels a guarded stage cannot
+// decide; the bit-exact stages over it reuse the first two.
+struct LinfitGuardBufs {
+    unsigned *list[3];
+    uint4 *state[3];
+    unsigned *count;              // device: [kLinfitCounters]
+    unsigned capacity;
+};
+struct LinfitGuardLists {          // where a guarded stage hands its undecidable pixels over
+    unsigned *x_list; unsigned *x_count; uint4 *x_state; unsigned x_capacity;
+};
+struct LinfitStage;
+int linfit_guard_supported(int mode, int n_frames, int64_t npix);
+hipError_t launch_stack_linfit_guarded(const StackArgs &args, const FastArgs &fargs, const LinfitGuardBufs &bufs,
+                                       hipStream_t stream, const char **name, hipEvent_t dominant_done);
+// one continuation stage of the bit-exact one-lane kernel over stage.in_list (stack_linfit.hip)
+void launch_linfit_exact_stage(const StackArgs &args, const FastArgs &fargs, const LinfitStage &stage, unsigned blocks,
+                               hipStream_t stream);
 
 hipError_t launch_stack_linfit_fast(const StackArgs &args, const FastArgs &fargs, const LinfitCascade *cascade,
                                     hipStream_t stream, const char **name, hipEvent_t dominant_done);

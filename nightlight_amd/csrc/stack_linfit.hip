@@ -17,61 +17,9 @@
 // MeanStdDev of xs = 0..m-1 depends on m only and comes from the host table.
 #include <cstdio>
 #include <cstdlib>
-#include "fast_ml_common.hpp"
+#include "linfit_common.hpp"
 
 namespace nl {
-
-__device__ __forceinline__ float sqrt_go(float x)      // float32(math.Sqrt(float64(x))), stats.go:259
-{
-    return (float)__builtin_sqrt((double)x);
-}
-
-// These make the compiler forget what it knows about a value (no instruction is
-// emitted).  Used between the passes of an iteration: otherwise it keeps the
-// 128 per-sample liveness factors and the 128 differences x-ymean of one pass
-// in registers for the next pass instead of recomputing them (2-3x the VGPRs).
-__device__ __forceinline__ float opaque_f(float x) { asm volatile("" : "+v"(x)); return x; }
-__device__ __forceinline__ unsigned opaque_u(unsigned x) { asm volatile("" : "+v"(x)); return x; }
-template <int NW>
-__device__ __forceinline__ void forget_words(unsigned (&w)[NW])
-{
-    static_assert(NW <= 4, "at most 128 samples");
-    asm volatile("" : "+v"(w[0]));
-    if constexpr (NW > 1) asm volatile("" : "+v"(w[1]));
-    if constexpr (NW > 2) asm volatile("" : "+v"(w[2]));
-    if constexpr (NW > 3) asm volatile("" : "+v"(w[3]));
-}
-
-// the chunk classes are wave-uniform: a volatile asm in each arm keeps the compiler from
-// if-converting the scalar branches (it would execute both arms and select)
-#define NL_KEEP_BRANCH asm volatile("")
-
-__device__ __forceinline__ float max3_asm(float a, float b, float c)
-{
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float min3_asm(float a, float b, float c)
-{
-    float r;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// 1 if x < 0 (sign bit), else 0 -- integer arithmetic on purpose: a compare
-// would produce a lane mask in SGPRs per element
-__device__ __forceinline__ unsigned sign_bit(float x) { return (unsigned)__float_as_int(x) >> 31; }
-
-// CONT = false: first stage, the grid covers the tile.  CONT = true: continuation
-// stage, grid-stride over the pixels the previous stage handed over; their
-// liveness masks come from memory (the sorted column is re-created: sorting is
-// deterministic, so the mask positions still mean the same samples).
-struct LinfitStage {
-    const unsigned *in_list;  const unsigned *in_count;  const uint4 *in_state;  unsigned in_capacity;
-    unsigned *out_list;       unsigned *out_count;       uint4 *out_state;       unsigned out_capacity;
-    int max_iters;            // fit iterations this stage may run per pixel (0: unlimited)
-};
 
 #ifndef NL_LF_CHUNK
 #define NL_LF_CHUNK 8
@@ -806,6 +754,20 @@ static void launch_lf(const StackArgs &args, const FastArgs &f, const LinfitCasc
             hipLaunchKernelGGL((stack_linfit_fast_kernel<NS, true>), dim3(gblocks), dim3(256), 0, stream, args, f, g);
         }
     }
+}
+
+// one continuation stage of the one-lane kernel over stage.in_list (the bit-exact tail of other cascades)
+void launch_linfit_exact_stage(const StackArgs &args, const FastArgs &fargs, const LinfitStage &stage, unsigned blocks,
+                               hipStream_t stream)
+{
+    const int n = args.n_frames;
+    if (n <= 8)        hipLaunchKernelGGL((stack_linfit_fast_kernel<8, true>), dim3(blocks), dim3(256), 0, stream, args, fargs, stage);
+    else if (n <= 16)  hipLaunchKernelGGL((stack_linfit_fast_kernel<16, true>), dim3(blocks), dim3(256), 0, stream, args, fargs, stage);
+    else if (n <= 32)  hipLaunchKernelGGL((stack_linfit_fast_kernel<32, true>), dim3(blocks), dim3(256), 0, stream, args, fargs, stage);
+    else if (n <= 48)  hipLaunchKernelGGL((stack_linfit_fast_kernel<48, true>), dim3(blocks), dim3(256), 0, stream, args, fargs, stage);
+    else if (n <= 64)  hipLaunchKernelGGL((stack_linfit_fast_kernel<64, true>), dim3(blocks), dim3(256), 0, stream, args, fargs, stage);
+    else if (n <= 96)  hipLaunchKernelGGL((stack_linfit_fast_kernel<96, true>), dim3(blocks), dim3(256), 0, stream, args, fargs, stage);
+    else               hipLaunchKernelGGL((stack_linfit_fast_kernel<128, true>), dim3(blocks), dim3(256), 0, stream, args, fargs, stage);
 }
 
 hipError_t launch_stack_linfit_fast(const StackArgs &args, const FastArgs &fargs, const LinfitCascade *cascade,

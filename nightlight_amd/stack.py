@@ -171,8 +171,8 @@ class StackHandle:
     @property
     def linfit_stage_counts(self):
         """list lengths of the last linear-fit cascade (see include/nlstack.h); [] if none ran"""
-        buf = (C.c_uint * 4)()
-        k = int(self._lib.nl_stack_linfit_stage_counts(self._h, buf, 4))
+        buf = (C.c_uint * 8)()
+        k = int(self._lib.nl_stack_linfit_stage_counts(self._h, buf, 8))
         return [int(buf[i]) for i in range(max(k, 0))]
 
     @property

@@ -66,11 +66,15 @@ const char *nl_last_error(void);
 int nl_device_count(void);
 /* library version string */
 const char *nl_version(void);
-/* nl_stack_destroy parks the large device buffers of a handle (frames, result, hand-over lists; at most 16 blocks and
- * NL_MEM_CACHE_MB MiB in all -- default 16 384, 0 turns the cache off) for the next nl_stack_create / nl_group_create of the
- * same geometry on the same device: a drop-in that creates one handle per OpStack.Apply (stack.go:131-138 allocates per
+/* nl_stack_destroy parks the large device buffers of a handle (frames, result, hand-over lists, the scratch of the
+ * winsorized / linear-fit cascades and of weighted passes; at most 16 blocks and NL_MEM_CACHE_MB MiB in all -- default:
+ * a sixteenth of the device's memory, 0 turns the cache off) for the next nl_stack_create / nl_group_create of the same
+ * geometry on the same device: a drop-in that creates one handle per OpStack.Apply (stack.go:131-138 allocates per
  * call, too) otherwise pays more for hipMalloc + hipFree than for the stack pass.  This returns the parked buffers to
- * HIP (also done automatically when an allocation fails).  No counterpart in the reference. */
+ * HIP.  The library does so itself whenever ANY of its own device allocations fails (every one of them goes through
+ * one helper that releases the cache and retries); allocations of OTHER code in the process (torch, RCCL) do not see
+ * the parked blocks as free memory -- call this, or set NL_MEM_CACHE_MB=0, when the process shares the device.
+ * No counterpart in the reference. */
 void nl_release_cached_memory(void);
 
 /* ---- handle: replaces the per-call state of OpStack.Apply (stack.go:115-227) ---- */

@@ -70,7 +70,7 @@ constexpr size_t kScratchBytes = sizeof(unsigned long long) * nl::kScratchWords;
 // The cgo drop-in creates a handle per OpStack.Apply (stack.go:131-138 allocates per call as well) and destroys it
 // afterwards: hipMalloc + hipFree of the frame buffer alone cost more than the headline pass (measured, bench.py
 // "fresh_handle": create 1.0 - 1.6 ms, destroy 1.3 - 1.8 ms, pass 1.7 ms).  The large buffers of a destroyed handle are
-// therefore parked -- at most kCacheBlocks of them, NL_MEM_CACHE_MB MiB in all (default 16 384; 0 = off) -- and the
+// therefore parked -- at most kCacheBlocks of them, NL_MEM_CACHE_MB MiB in all (default: a sixteenth of the device's memory; 0 = off) -- and the
 // next handle with the same sizes on the same device takes them over.  nl_release_cached_memory() returns them to HIP.
 constexpr int kCacheBlocks = 16;
 constexpr size_t kCacheMinBytes = (size_t)1 << 20;
@@ -79,12 +79,19 @@ std::mutex g_cache_mu;
 std::vector<CachedBlock> g_cache;
 size_t g_cache_bytes = 0;
 
+// Limit of the parked bytes: NL_MEM_CACHE_MB if set (0 = off), else a sixteenth of the device's memory (18 GB of an
+// MI355X's 288: the frame buffer of the headline stack is 8 GiB) -- blocks parked by this library are invisible to the
+// other allocators of the process (torch, RCCL) until an allocation of OURS fails, so the default stays small.
 size_t cache_limit()
 {
     static const size_t lim = [] {
-        const char *e = getenv("NL_MEM_CACHE_MB");
-        const long long mb = e ? atoll(e) : 16384;
-        return mb > 0 ? (size_t)mb << 20 : (size_t)0;
+        if (const char *e = getenv("NL_MEM_CACHE_MB")) {
+            const long long mb = atoll(e);
+            return mb > 0 ? (size_t)mb << 20 : (size_t)0;
+        }
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return (size_t)4096 << 20; }
+        return total_b / 16;
     }();
     return lim;
 }
@@ -103,6 +110,22 @@ void cache_release_all()
     (void)hipSetDevice(cur);
 }
 
+// EVERY device allocation of the library goes through here: when HIP is out of memory while blocks are parked, they are
+// handed back and the allocation is tried again (the caller has selected the device).
+hipError_t dev_malloc(void **p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) return e;
+    bool parked;
+    { std::lock_guard<std::mutex> lk(g_cache_mu); parked = !g_cache.empty(); }
+    if (!parked) return e;
+    (void)hipGetLastError();
+    cache_release_all();
+    return hipMalloc(p, bytes);
+}
+template <class T>
+hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc(reinterpret_cast<void **>(p), bytes); }
+
 // (the caller has selected `device`)
 hipError_t cached_malloc(void **p, size_t bytes, int device)
 {
@@ -116,13 +139,7 @@ hipError_t cached_malloc(void **p, size_t bytes, int device)
                 return hipSuccess;
             }
     }
-    hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess && !g_cache.empty()) {             // out of memory with blocks parked: give them back and retry
-        (void)hipGetLastError();
-        cache_release_all();
-        e = hipMalloc(p, bytes);
-    }
-    return e;
+    return dev_malloc(p, bytes);
 }
 
 void cached_free(void *p, size_t bytes, int device)
@@ -323,8 +340,8 @@ static int destroy_impl(nl_stack_t *h)
     if (h->d_weights) (void)hipFree(h->d_weights);
     if (h->d_xstat) (void)hipFree(h->d_xstat);
     if (h->d_sets) (void)hipFree(h->d_sets);
-    if (h->d_bounds) (void)hipFree(h->d_bounds);
-    if (h->d_nrounds) (void)hipFree(h->d_nrounds);
+    cached_free(h->d_bounds, (size_t)nl::kBoundRounds * (size_t)h->npix * sizeof(float2), h->device);
+    cached_free(h->d_nrounds, (size_t)h->npix, h->device);
     cached_free(h->d_fb_list, sizeof(unsigned) * (size_t)h->npix, h->device);
     cached_free(h->d_gen_list, sizeof(unsigned) * (size_t)h->npix, h->device);
     if (h->d_cols) cached_free(h->d_cols, h->cols_bytes, h->device);
@@ -388,9 +405,9 @@ static int create_impl(nl_stack_t *h)
     NL_HIP(cached_malloc((void **)&h->d_frames_owned, frame_bytes * (size_t)h->n_frames, h->device));
     h->d_frames = h->d_frames_owned;
     NL_HIP(cached_malloc((void **)&h->d_out, frame_bytes, h->device));
-    NL_HIP(hipMalloc(&h->d_weights, sizeof(float) * (size_t)h->n_frames));
+    NL_HIP(dev_malloc(&h->d_weights, sizeof(float) * (size_t)h->n_frames));
     h->max_grid = 256 * 64;
-    NL_HIP(hipMalloc(&h->d_sets, 2 * kScratchBytes));
+    NL_HIP(dev_malloc(&h->d_sets, 2 * kScratchBytes));
     NL_HIP(hipMemsetAsync(h->d_sets, 0, 2 * kScratchBytes, h->stream));
     h->cur_set = 0;
     h->d_partial = h->d_sets;
@@ -399,9 +416,9 @@ static int create_impl(nl_stack_t *h)
         NL_HIP(cached_malloc((void **)&h->d_fb_list, sizeof(unsigned) * (size_t)h->npix, h->device));
         NL_HIP(cached_malloc((void **)&h->d_gen_list, sizeof(unsigned) * (size_t)h->npix, h->device));
     }
-    NL_HIP(hipMalloc(&h->d_counters, sizeof(unsigned long long) * 4));      // {clip_low, clip_high, list lengths (fused passes), -}
+    NL_HIP(dev_malloc(&h->d_counters, sizeof(unsigned long long) * 4));      // {clip_low, clip_high, list lengths (fused passes), -}
     NL_HIP(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * 4, h->stream));
-    NL_HIP(hipMalloc(&h->d_stat_partial, sizeof(double) * 3 * kStatBlocks));
+    NL_HIP(dev_malloc(&h->d_stat_partial, sizeof(double) * 3 * kStatBlocks));
 
     // stats.MeanStdDev over xs = 0..n-1 (stats.go:246-261, called from :570)
     // depends on n only: tabulate it once, in the same fp32 operation order.
@@ -420,7 +437,7 @@ static int create_impl(nl_stack_t *h)
         xstat[2 * (size_t)n] = mean;
         xstat[2 * (size_t)n + 1] = (float)sqrt((double)var);
     }
-    NL_HIP(hipMalloc(&h->d_xstat, xstat.size() * sizeof(float)));
+    NL_HIP(dev_malloc(&h->d_xstat, xstat.size() * sizeof(float)));
     NL_HIP(hipMemcpy(h->d_xstat, xstat.data(), xstat.size() * sizeof(float), hipMemcpyHostToDevice));
     return NL_OK;
 }
@@ -712,7 +729,7 @@ static bool linfit_buffers(nl_stack_t *h, int lists = 2)
         // sized for the most lanes per pixel any active frame count of this handle can need
         h->lf_lanes = h->n_capacity <= 128 ? 1 : h->n_capacity <= 256 ? 2 : 4;
         h->lf_tried = true;
-        if (hipMalloc(&h->d_lf_count, sizeof(unsigned) * nl::kLinfitCounters) != hipSuccess) {
+        if (dev_malloc(&h->d_lf_count, sizeof(unsigned) * nl::kLinfitCounters) != hipSuccess) {
             (void)hipGetLastError();
             h->d_lf_count = nullptr;
         }
@@ -805,10 +822,12 @@ static bool ensure_bounds(nl_stack *h)
     if (h->d_bounds) return true;
     if (h->bounds_tried) return false;
     h->bounds_tried = true;
-    if (hipMalloc(&h->d_bounds, (size_t)nl::kBoundRounds * (size_t)h->npix * sizeof(float2)) != hipSuccess ||
-        hipMalloc(&h->d_nrounds, (size_t)h->npix) != hipSuccess) {
+    // (through the cache: a handle per Apply of a weighted stack pays no hipMalloc / hipFree of 1.1 GB at 4096^2)
+    if (cached_malloc((void **)&h->d_bounds, (size_t)nl::kBoundRounds * (size_t)h->npix * sizeof(float2), h->device) != hipSuccess ||
+        cached_malloc((void **)&h->d_nrounds, (size_t)h->npix, h->device) != hipSuccess) {
         (void)hipGetLastError();
         if (h->d_bounds) { (void)hipFree(h->d_bounds); h->d_bounds = nullptr; }
+        h->d_nrounds = nullptr;
         return false;
     }
     return true;
@@ -884,7 +903,7 @@ static int ensure_chunk_resources(nl_stack *h)
         NL_HIP(hipEventCreateWithFlags(&h->ev_chunk_join[i], hipEventDisableTiming));
     }
     for (int i = 0; i < kMaxChunks; i++) NL_HIP(hipEventCreateWithFlags(&h->ev_chunk[i], hipEventDisableTiming));
-    NL_HIP(hipMalloc(&h->d_chunk_counts, sizeof(unsigned) * 4 * kMaxChunks));
+    NL_HIP(dev_malloc(&h->d_chunk_counts, sizeof(unsigned) * 4 * kMaxChunks));
     return NL_OK;
 }
 
@@ -1712,7 +1731,7 @@ int nl_stack_find_sigmas(nl_stack_t *h, int mode, float ref_loc,
 int nl_stack_accumulate(nl_stack_t *h, float weight, int first)
 {
     NL_CHECK_HANDLE(h);
-    if (!h->d_acc) NL_HIP(hipMalloc(&h->d_acc, (size_t)h->npix * sizeof(float)));
+    if (!h->d_acc) NL_HIP(dev_malloc(&h->d_acc, (size_t)h->npix * sizeof(float)));
     NL_HIP(nl::launch_axpy(h->d_acc, h->d_out, weight, first, h->npix, h->stream));
     NL_HIP(hipStreamSynchronize(h->stream));
     return NL_OK;
@@ -1823,7 +1842,7 @@ static int ingest_reserve(nl_stack_t *h, size_t bytes)
 {
     if (bytes <= h->ingest_bytes) return NL_OK;
     if (h->d_ingest) { (void)hipFree(h->d_ingest); h->d_ingest = nullptr; h->ingest_bytes = 0; }
-    NL_HIP(hipMalloc(&h->d_ingest, bytes));
+    NL_HIP(dev_malloc(&h->d_ingest, bytes));
     h->ingest_bytes = bytes;
     return NL_OK;
 }
@@ -1917,11 +1936,11 @@ int nl_stack_upload_frame_projected(nl_stack_t *h, int idx, const float *src_hos
 // every frame in flight)
 static int ingest_async_reserve(nl_stack_t *h, size_t bytes)
 {
-    if (!h->d_stat_partial_async) NL_HIP(hipMalloc(&h->d_stat_partial_async, sizeof(double) * 3 * kStatBlocks));
+    if (!h->d_stat_partial_async) NL_HIP(dev_malloc(&h->d_stat_partial_async, sizeof(double) * 3 * kStatBlocks));
     if (h->ingest_async_bytes >= bytes) return NL_OK;
     if (h->copy_stream) NL_HIP(hipStreamSynchronize(h->copy_stream));
     if (h->d_ingest_async) { NL_HIP(hipFree(h->d_ingest_async)); h->d_ingest_async = nullptr; h->ingest_async_bytes = 0; }
-    NL_HIP(hipMalloc(&h->d_ingest_async, bytes));
+    NL_HIP(dev_malloc(&h->d_ingest_async, bytes));
     h->ingest_async_bytes = bytes;
     return NL_OK;
 }
@@ -2040,8 +2059,8 @@ int nl_median_filter_mask(const float *in_host, float *out_host, int64_t n, cons
     NL_HIP(hipSetDevice(device));
     const size_t bytes = (size_t)n * sizeof(float);
     float *d_in = nullptr, *d_out = nullptr;
-    NL_HIP(hipMalloc(&d_in, bytes));
-    hipError_t e = hipMalloc(&d_out, bytes);
+    NL_HIP(dev_malloc(&d_in, bytes));
+    hipError_t e = dev_malloc(&d_out, bytes);
     if (e != hipSuccess) { (void)hipFree(d_in); return fail(NL_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
     do {
         if ((e = hipMemcpy(d_in, in_host, bytes, hipMemcpyHostToDevice)) != hipSuccess) break;
@@ -2064,8 +2083,8 @@ int nl_median_filter_3x3(const float *in_host, float *out_host, int width, int h
     NL_HIP(hipSetDevice(device));
     const size_t bytes = (size_t)width * height * sizeof(float);
     float *d_in = nullptr, *d_out = nullptr;
-    NL_HIP(hipMalloc(&d_in, bytes));
-    hipError_t e = hipMalloc(&d_out, bytes);
+    NL_HIP(dev_malloc(&d_in, bytes));
+    hipError_t e = dev_malloc(&d_out, bytes);
     if (e != hipSuccess) { (void)hipFree(d_in); return fail(NL_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
     int rc = NL_OK;
     do {

@@ -7,6 +7,7 @@
 //                   :97-147 (SIMPLE, BITPIX, NAXIS, NAXISn mandatory; BZERO, BSCALE, EXPOSURE / EXPTIME optional)
 //   header writer   internal/fits/write.go:54-89 (the cards Image.Write emits, END, padding with spaces),
 //                   :104-147 ("%-8s= %20s / %-47s", %g of a float32)
+#include <errno.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -104,8 +105,7 @@ Card parse_card(const char *line)
     return c;
 }
 
-// fmt's %g of a float32: shortest digits that round-trip, %e form when the exponent is < -4 or >= 21 digits ... for the
-// shortest form Go decides with a precision of 6: exponent < -4 || exponent >= max(digits, 6) -> d.ddde+XX
+// fmt's %g of a float32: shortest digits that round-trip; %e form (d.ddde+XX) when the decimal exponent is < -4 or >= 6
 std::string go_g(float v)
 {
     if (v != v) return "NaN";
@@ -127,9 +127,9 @@ std::string go_g(float v)
     std::string digits;
     for (char ch : mant) if (ch != '.') digits += ch;
     while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
-    int eprec = 6;
-    if ((int)digits.size() > eprec) eprec = (int)digits.size();
-    if (exp < -4 || exp >= eprec) {
+    // strconv's %e decision for the SHORTEST form uses a precision of 6 whatever the number of digits (ftoa.go: `if
+    // shortest { eprec = 6 }` comes after the digit-count adjustment): float32(1234567) -> 1.234567e+06
+    if (exp < -4 || exp >= 6) {
         std::string out = sign + digits.substr(0, 1);
         if (digits.size() > 1) out += "." + digits.substr(1);
         char e[16];
@@ -200,16 +200,28 @@ int nl_fits_parse_header(const void *file_bytes, int64_t n_bytes, int id, nl_fit
     if (!have_naxis) return fail(NL_ERR_INVALID_ARG, std::to_string(id) + ": FITS header does not contain key NAXIS");
     if (out->naxis < 0 || out->naxis > NL_FITS_MAX_AXES)
         return fail(NL_ERR_INVALID_ARG, std::to_string(id) + ": NAXIS " + std::to_string(out->naxis) + " not in [0, " + std::to_string(NL_FITS_MAX_AXES) + "]");
+    // (the reference trusts these fields and sizes its buffers from them; a C ABI fed with untrusted files does not:
+    // the BITPIX values read.go:172-445 decodes, no negative axis, no overflow of the byte counts)
+    switch (out->bitpix) {
+    case 8: case 16: case 32: case 64: case -32: case -64: break;
+    default: return fail(NL_ERR_INVALID_ARG, std::to_string(id) + ": unsupported BITPIX " + std::to_string(out->bitpix));
+    }
     int64_t pixels = 1;
     for (int a = 0; a < out->naxis; a++) {
         if (!have_n[a]) return fail(NL_ERR_INVALID_ARG, std::to_string(id) + ": FITS header does not contain key NAXIS" + std::to_string(a + 1));
-        pixels *= out->naxisn[a];
+        if (out->naxisn[a] < 0)
+            return fail(NL_ERR_INVALID_ARG, std::to_string(id) + ": negative NAXIS" + std::to_string(a + 1) + " " + std::to_string(out->naxisn[a]));
+        if (__builtin_mul_overflow(pixels, (int64_t)out->naxisn[a], &pixels))
+            return fail(NL_ERR_INVALID_ARG, std::to_string(id) + ": the NAXISn of the header overflow 63 bits");
     }
     if (!have_exposure && have_exptime) out->exposure = exptime;                 // read.go:135-139
-    int bytes_per = out->bitpix < 0 ? -out->bitpix / 8 : out->bitpix / 8;
+    const int64_t bytes_per = out->bitpix < 0 ? -out->bitpix / 8 : out->bitpix / 8;
+    int64_t payload = 0;
+    if (__builtin_mul_overflow(pixels, bytes_per, &payload) || payload > INT64_MAX - kBlock)
+        return fail(NL_ERR_INVALID_ARG, std::to_string(id) + ": the payload size of the header overflows 63 bits");
     out->pixels = pixels;
     out->header_bytes = length;
-    out->payload_bytes = pixels * bytes_per;
+    out->payload_bytes = payload;
     out->padded_payload_bytes = nl_fits_padded_bytes(out->payload_bytes);
     return NL_OK;
 }

@@ -121,6 +121,14 @@ def test_product_fits_framing_matches_the_reference_restatement(fits_files, tmp_
     assert b"EXPOSURE=                1e+06 /" in nla.fits_write_header([7, 5, 3], 0.5, 2.0, 1e6)          # fmt %g of a float32
     assert b"EXPOSURE=           0.33333334 /" in nla.fits_write_header([16], -1.0, 0.25, 1.0 / 3.0)     # shortest digits that round-trip
     assert b"BZERO   =                   -1 /" in nla.fits_write_header([16], -1.0, 0.25, 1.0 / 3.0)
+    # strconv decides %e for the shortest form with a precision of 6 whatever the digit count (ftoa.go): seven and eight
+    # significant digits at exponent >= 6 still take the exponent form
+    assert b"EXPOSURE=         1.234567e+06 /" in nla.fits_write_header([16], 0.0, 1.0, 1234567.0)
+    assert b"EXPOSURE=        1.6777216e+07 /" in nla.fits_write_header([16], 0.0, 1.0, 16777216.0)
+    assert b"EXPOSURE=               123456 /" in nla.fits_write_header([16], 0.0, 1.0, 123456.0)
+    assert b"EXPOSURE=             999999.9 /" in nla.fits_write_header([16], 0.0, 1.0, 999999.9)
+    assert b"BZERO   =               0.0001 /" in nla.fits_write_header([16], 1e-4, 1.0, 0.0)
+    assert b"BZERO   =                1e-05 /" in nla.fits_write_header([16], 1e-5, 1.0, 0.0)
     raw = open(paths[0], "rb").read()
     info = nla.fits_parse_header(raw, 7)
     oinfo, off = fitsio.read_header(paths[0])
@@ -150,6 +158,21 @@ def test_product_fits_framing_matches_the_reference_restatement(fits_files, tmp_
     with pytest.raises(capi.NlError) as e:
         nla.fits_parse_header(raw[:1000], 1)                     # no END inside the bytes given
     assert e.value.message == "1: unexpected EOF"
+    # untrusted headers: a negative axis, a BITPIX the decoder does not know, axes whose product overflows 63 bits
+    def with_card(key, value):
+        b = bytearray(raw[:2880])
+        i = b.index(key.ljust(8).encode() + b"=")
+        b[i:i + 80] = ("%-8s= %20s / %-47s" % (key, value, "")).encode()
+        return bytes(b)
+    for key, value, text in (("NAXIS1", "-4", "negative NAXIS1 -4"), ("BITPIX", "-16", "unsupported BITPIX -16"),
+                             ("BITPIX", "24", "unsupported BITPIX 24")):
+        with pytest.raises(capi.NlError) as e:
+            nla.fits_parse_header(with_card(key, value), 2)
+        assert e.value.message == "2: " + text
+    big = bytearray(nla.fits_write_header([2147483647] * 8, 0.0, 1.0, 0.0))
+    with pytest.raises(capi.NlError) as e:
+        nla.fits_parse_header(bytes(big), 4)
+    assert "overflow" in e.value.message
 
 
 @pytest.mark.gpu

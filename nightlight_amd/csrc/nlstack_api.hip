@@ -59,7 +59,7 @@ constexpr int kMaxChunks = 16;             // pixel ranges of a chunked pass
 // workgroup" for every stage (the last one runs to the end): measured on 4096^2 -- up to 40 frames
 // 16 / 24 frames 3.68 / 3.94 -> 2.97 / 3.07 ms, 41 ... 96 frames (64: 5.22 -> 4.59 ms); beyond that a continuing stage
 // re-reads every cache line of the stack for an eighth of its pixels and the cascade loses (128 frames: 5.43 -> 5.83 ms)
-constexpr const char *kWinsorPlanShallow = "1:8,1:12:4,2:16:4,0:0:4";
+constexpr const char *kWinsorPlanShallow = "1:6,1:12:4,2:16:4,0:0:4";   // (round 5, with the certificate: 1:8 -> 1:6, 16 frames 2.34 -> 2.18 ms)
 constexpr const char *kWinsorPlanDeep = "2:12,2:16:8,3:24:4,0:0:4";
 constexpr int kWinsorCascadeMaxFrames = 96;
 // per-pass device scratch, zeroed by one memset (or, in the fused protocol of the sigma / winsorized fast path, by
@@ -1276,6 +1276,15 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
             static const int cap_env = [] { const char *e = getenv("NL_GEN_ROUND_CAP"); return e ? atoi(e) : 0; }();
             // (measured per frame count on the bench stack; 12 / 13 frames -- the smallest stacks with a zonal kernel -- lose with 40)
             f.gen_round_cap = cap_env > 0 ? cap_env : (a.n_frames >= 48 ? 24 : (a.n_frames > 20 ? 32 : ((a.n_frames == 12 || a.n_frames == 13) ? 60 : 40)));
+        }
+        // the invariant-interval certificate of the winsorization loops (stack_fast_sigma_impl.hpp): first trial after
+        // cert_first rounds of a loop, then every cert_every; NL_WCERT="first,every" ("0" = off), developer switch 16384: off
+        // (3, 3: measured best at 16 frames and within 2 % of the best at 24, profiles/r05_winsor_cert.txt)
+        if (mode == NL_ST_WINSOR_SIGMA) {
+            static const int cert_env[2] = {[] { const char *e = getenv("NL_WCERT"); return e ? atoi(e) : 3; }(),
+                                            [] { const char *e = getenv("NL_WCERT"); const char *c = e ? strchr(e, ',') : nullptr; const int v = c ? atoi(c + 1) : 3; return v > 0 ? v : 1; }()};
+            f.cert_first = (h->dev_flags & 16384u) ? 0 : cert_env[0];
+            f.cert_every = cert_env[1];
         }
         // winsorized clipping of 16 ... 128 frames: the winsorization cascade (stack_fast_sigma_impl.hpp) -- the dominant
         // kernel and a second stage stop at a budget of rounds per wave and hand their unfinished pixels on, a third

@@ -35,6 +35,9 @@ namespace nl {
 // replayed from scratch as before.
 // CONT (zonal only): the kernel runs over q.in_list / q.in_state instead of the tile.
 
+#ifndef NL_CERT_ON
+#define NL_CERT_ON(ns) true
+#endif
 #ifndef NL_WINSOR_WL
 #define NL_WINSOR_WL(ns) ((ns) >= 112 ? 20 : ((ns) >= 80 ? 16 : ((ns) / 4 + 3) / 4 * 4))
 #endif
@@ -323,6 +326,46 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
             pick_pair<W0, W1>(v, kk, lower, upper);
             const float median = (cnt & 1) ? upper : 0.5f * (lower + upper);
 
+            // ---- the reference's bound expressions at both ends of an interval [smin, smax] of its stddev (stack.go:408-409;
+            // fp32 multiply then add, never fused), and the certain (c1, d1) / possible (c2, d2) clips they imply.  The
+            // column is sorted, so the samples below a threshold are a prefix and those above it a suffix (pads are
+            // +Inf): counted over the whole zone without rank masks, minus what is already excluded ----
+            float lo_min, lo_max, hi_min, hi_max;
+            auto clip_counts = [&](const float smin, const float smax, int &c1, int &c2, int &d1, int &d2) NL_INL {
+                const float tl0 = __fmul_rn(p.sig_lo, smin), tl1 = __fmul_rn(p.sig_lo, smax);
+                const float th0 = __fmul_rn(p.sig_hi, smin), th1 = __fmul_rn(p.sig_hi, smax);
+                const float la = __fsub_rn(median, tl0), lb = __fsub_rn(median, tl1);
+                const float ha = __fadd_rn(median, th0), hb = __fadd_rn(median, th1);
+                lo_min = fminf(la, lb); lo_max = fmaxf(la, lb);
+                hi_min = fminf(ha, hb); hi_max = fmaxf(ha, hb);
+                c1 = 0; c2 = 0; d1 = 0; d2 = 0;
+                if constexpr (ZONAL) {
+                    static_range<0, ZL>([&](auto K) NL_INL {
+                        constexpr int k = decltype(K)::value;
+                        c1 += (v[k] < lo_min) ? 1 : 0;
+                        c2 += (v[k] < lo_max) ? 1 : 0;
+                    });
+                    static_range<ZH, NS>([&](auto K) NL_INL {
+                        constexpr int k = decltype(K)::value;
+                        d1 += (v[k] > hi_max) ? 1 : 0;
+                        d2 += (v[k] > hi_min) ? 1 : 0;
+                    });
+                    c1 = max(c1 - a, 0); c2 = max(c2 - a, 0);
+                    d1 = max(d1 - (NS - b), 0); d2 = max(d2 - (NS - b), 0);
+                } else {
+                    static_chunks<0, NS, 8>([&](auto K) NL_INL {
+                        constexpr int k = decltype(K)::value;
+                        const float x = v[k];
+                        c1 += (x < lo_min) ? 1 : 0;
+                        c2 += (x < lo_max) ? 1 : 0;
+                        d1 += (x > hi_max) ? 1 : 0;
+                        d2 += (x > hi_min) ? 1 : 0;
+                    });
+                    c1 = min(max(c1 - a, 0), cnt); c2 = min(max(c2 - a, 0), cnt);
+                    d1 = min(max(d1 - (NS - b), 0), cnt); d2 = min(max(d2 - (NS - b), 0), cnt);
+                }
+            };
+
             if constexpr (WINSOR) {
                 // ---- winsorized stddev, stack.go:646-672, as an interval ----
                 // The reference repeats { clamp a copy to median -/+ 1.5*std; std =
@@ -338,7 +381,28 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
                 wi.start(s_min, s_max, ((!ZONAL || CONT) && q.gen_round_cap > 0) ? q.gen_round_cap : 100);
                 bool inner = active && !bail;
                 int rounds_left = (CASCADE && q.round_cap > 0) ? q.round_cap : 0x7fffffff;
+                // (round 5) INVARIANT-INTERVAL CERTIFICATE.  The loop is monotone: the clamps only tighten, and the variance
+                // of the clamped copy is monotone in the clamp.  Let L <= (every possible value of) the current std, and let
+                // the lower end of the NEXT std's interval, evaluated at the clamp L itself would produce -- tighter than any
+                // clamp a std >= L can produce, composed with the clamps so far -- be >= L.  Then by induction every later
+                // std of the reference is >= L, and w_hi bounds them from above (clamps at least as tight as today's
+                // loosest): wherever the reference leaves its loop, its std lies in [L, w_hi].  If the clip decisions agree
+                // over that interval (and over what the hull already holds) the loop is left NOW.  L is an Aitken
+                // extrapolation of the last three lower ends with a margin; a failed trial costs one evaluation.
+                // tools/winsor_cert_sim.py: rounds per lock-step wave 46 -> 27 at 16 frames, 38 -> 24 at 24, 25 -> 20 at 128.
+                // A trial is an iteration of the SAME loop -- the one evaluation of the clamped variance, at the trial's clamp
+                // instead of the round's: a second inlined copy of that evaluation took the 128-position kernel from 165 to 237
+                // registers (two waves per SIMD instead of three: 4.5 -> 5.7 ms).
+                constexpr bool CERT = NL_CERT_ON(NS) && (ZONAL || NS <= 32) && !RECORD;
+                float wl_h0 = s_min, wl_h1 = s_min;        // lower ends of the std one and two rounds ago
+                int wr = 0;
+                bool trial_next = false;                   // wave-uniform
                 while (__any(inner)) {
+                    const bool is_trial = CERT && trial_next;
+                    trial_next = false;
+                    float Lc, Hc, ltry = 0.0f;
+                    bool trial = false;
+                    if (!is_trial) {
                     if constexpr (CASCADE) {
                         if (rounds_left <= 0) {            // at the cap: these lanes re-enter this pass in the next stage
                             defer = defer || inner;
@@ -348,7 +412,22 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
                         rounds_left--;
                     }
                     if (ZONAL) { if (lane == 0) NL_STAT(0, 1); if (inner) NL_STAT(1, 1); }
+                    wl_h0 = wl_h1; wl_h1 = wi.w_lo;
                     wi.next_clamp(median, xmin, xmax);
+                    Lc = wi.Lp; Hc = wi.Hm;
+                    } else {
+                        const float s2 = wi.w_lo, s1 = wl_h1, s0 = wl_h0;
+                        const float dd1 = s1 - s2, dd0 = s0 - s1;
+                        float rr = dd1 * __builtin_amdgcn_rcpf(dd0);
+                        rr = fminf(fmaxf(rr, 0.0f), 0.95f);
+                        const float rest = dd1 * rr * __builtin_amdgcn_rcpf(1.0f - rr);
+                        ltry = fmaxf(s2 - 1.5f * rest - 1.0e-4f * s2, 0.0f);
+                        trial = inner && dd1 > 0.0f && dd0 > 0.0f && ltry > 0.0f && ltry <= s2;
+                        // the clamp the value ltry itself would produce (the reference's own operations: monotone in the std)
+                        const float tq = __fmul_rn(1.5f, ltry);
+                        Lc = fmaxf(wi.Lp, __fsub_rn(median, tq));
+                        Hc = fminf(wi.Hm, __fadd_rn(median, tq));
+                    }
                     // variance of clamp(x, Lt, Ht) over the survivors (shifted moments) and its error bound
                     auto clamped_variance = [&](const float Lt, const float Ht, float &wvar, float &werr, float &wmean_c,
                                                 float &wrms) NL_INL {
@@ -413,7 +492,22 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
                     wrms = wa;                                     // E[(copy - c)^2]
                     };
                     float var_t, err_t, wd_t, wa_t;
-                    clamped_variance(wi.Lp, wi.Hm, var_t, err_t, wd_t, wa_t);
+                    clamped_variance(Lc, Hc, var_t, err_t, wd_t, wa_t);
+                    if (is_trial) {
+                        const float x_dn = fmaxf(var_t - err_t, 0.0f);
+                        const float x_lo = __builtin_amdgcn_sqrtf(fmaxf(x_dn - x_dn * eps_r, 0.0f)) * (1.0f - 4.0f * kU);
+                        trial = trial && __fmul_rn(1.134f, x_lo) >= ltry && (!ZONAL || (v[WL] >= Lc && v[WH - 1] <= Hc));
+                        // every value the reference may leave the loop with: what the hull holds, and [ltry, w_hi]
+                        const float h_lo = fminf(wi.hull_lo, ltry), h_hi = fmaxf(wi.hull_hi, wi.w_hi);
+                        int e1, e2, f1, f2;
+                        clip_counts(h_lo, h_hi, e1, e2, f1, f2);
+                        trial = trial && e1 == e2 && f1 == f2 && h_hi < 3.0e38f;
+                        if (trial) {
+                            wi.hull_lo = h_lo; wi.hull_hi = h_hi;
+                            inner = false;
+                        }
+                        continue;
+                    }
                     // The loosest clamp (Lm, Hp) is not evaluated: with y = the copy at the tightest
                     // clamp and z = the copy at the loosest, z - y = delta is non-zero only for the
                     // n_lo samples below Lp (delta in [-(Lp-Lm), 0], y = Lp there) and the n_hi samples
@@ -468,38 +562,17 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
                     // zonal: the inner half must be strictly inside every clamp of the interval
                     const bool shape_ok = !ZONAL || (v[WL] >= wi.Lp && v[WH - 1] <= wi.Hm);
                     wi.finish_round(var_t, err_t, var_l, err_l, eps_r, e_m, shape_ok, inner, bail);
+                    wr++;
+                    if constexpr (CERT) trial_next = q.cert_first > 0 && wr >= q.cert_first && ((wr - q.cert_first) % q.cert_every) == 0;
                 }
                 s_min = wi.hull_lo;
                 s_max = wi.hull_hi;
             }
 
-            // ---- the reference's bound expressions at both ends of the interval ----
-            // (stack.go:408-409; fp32 multiply then add, never fused)
-            const float tl0 = __fmul_rn(p.sig_lo, s_min), tl1 = __fmul_rn(p.sig_lo, s_max);
-            const float th0 = __fmul_rn(p.sig_hi, s_min), th1 = __fmul_rn(p.sig_hi, s_max);
-            const float la = __fsub_rn(median, tl0), lb = __fsub_rn(median, tl1);
-            const float ha = __fadd_rn(median, th0), hb = __fadd_rn(median, th1);
-            const float lo_min = fminf(la, lb), lo_max = fmaxf(la, lb);
-            const float hi_min = fminf(ha, hb), hi_max = fmaxf(ha, hb);
-
-            // ---- count certain clips (c1,d1) and possible clips (c2,d2) ----
-            // The column is sorted, so the samples below a threshold are a prefix and
-            // those above it a suffix (pads are +Inf): count over the whole zone
-            // without rank masks and subtract what is already excluded.
-            int c1 = 0, c2 = 0, d1 = 0, d2 = 0;
+            // ---- count certain clips (c1,d1) and possible clips (c2,d2) over the interval of the stddev ----
+            int c1, c2, d1, d2;
+            clip_counts(s_min, s_max, c1, c2, d1, d2);
             if constexpr (ZONAL) {
-                static_range<0, ZL>([&](auto K) NL_INL {
-                    constexpr int k = decltype(K)::value;
-                    c1 += (v[k] < lo_min) ? 1 : 0;
-                    c2 += (v[k] < lo_max) ? 1 : 0;
-                });
-                static_range<ZH, NS>([&](auto K) NL_INL {
-                    constexpr int k = decltype(K)::value;
-                    d1 += (v[k] > hi_max) ? 1 : 0;
-                    d2 += (v[k] > hi_min) ? 1 : 0;
-                });
-                c1 = max(c1 - a, 0); c2 = max(c2 - a, 0);
-                d1 = max(d1 - (NS - b), 0); d2 = max(d2 - (NS - b), 0);
                 // the zones must still hold a survivor on each side, otherwise the
                 // next sorted position (outside the zone) might be clipped as well:
                 // such a lane restarts in the generic pass
@@ -507,17 +580,6 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
                     to_generic = true;
                     active = false;
                 }
-            } else {
-                static_chunks<0, NS, 8>([&](auto K) NL_INL {
-                    constexpr int k = decltype(K)::value;
-                    const float x = v[k];
-                    c1 += (x < lo_min) ? 1 : 0;
-                    c2 += (x < lo_max) ? 1 : 0;
-                    d1 += (x > hi_max) ? 1 : 0;
-                    d2 += (x > hi_min) ? 1 : 0;
-                });
-                c1 = min(max(c1 - a, 0), cnt); c2 = min(max(c2 - a, 0), cnt);
-                d1 = min(max(d1 - (NS - b), 0), cnt); d2 = min(max(d2 - (NS - b), 0), cnt);
             }
             if (active) {
                 // a sample inside the window, or (negative sigma) inverted bounds where the

@@ -102,6 +102,7 @@ struct FastArgs {
     long long cols_stride = 0;
     // The same class as PERSISTENT workgroups (three per CU, each looping over blocks of 64 pixels; the rounds of a block run in one
     // of its waves while the others are sorting the next block -- stack_fast_mlz_impl.hpp, PHASE 3).  0: one workgroup per block.
+    int cert_first = 0, cert_every = 1;      // invariant-interval certificate of the winsorization loops (stack_fast_sigma_impl.hpp): first trial after this many rounds of a loop (0: off), then every so many
     int gen_round_cap = 0;        // generic pass of the one-lane winsorized kernels: winsorization rounds per clipping pass before a pixel
                                   // is handed to the exact replay instead (0: 100, the limit of every kernel)
     int persistent = 0;

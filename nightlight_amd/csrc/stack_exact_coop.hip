@@ -375,8 +375,14 @@ __device__ float coop_select_median(float *a, unsigned short *lpos, unsigned sho
 // pixels are replayed one after the other.  One pixel at a time fetched 13 x the algorithmic bytes (4 bytes out
 // of every 64-byte sector, with 16 MB of lines in flight per XCD against 4 MB of L2) and the replay ran at the
 // speed of those fetches.
-template <bool WINSOR, bool W, int GROUP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void stack_sigma_coop_kernel(StackArgs p)
+// PF: chunks of 64 frames a work item holds in registers before it replays its pixels (GROUP = 4: as 16-byte loads of
+// all four).  Round 5: deep weighted stacks took PF = 2 like everything else and fetched the frames beyond 128 four bytes
+// at a time, once per pixel -- 13.7 x the algorithmic bytes at 512 frames, 3.4 TB/s of mostly unused sectors
+// (profiles/r04_wsigma512_*).  With PF = 8 (257 ... 512 frames) every frame of the four pixels arrives in one 16-byte load
+// per lane; the registers cost wave slots the LDS columns of those depths had taken already.  Dispatched for the
+// winsorized replays only, see launch_coop.
+template <bool WINSOR, bool W, int GROUP, int PF = 2>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PF <= 2 ? 8 : 5, 8))) void stack_sigma_coop_kernel(StackArgs p)
 {
     extern __shared__ float a[];
     float *wz = a + p.n_frames;                   // winsorized copy (WINSOR only)
@@ -416,9 +422,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     if (!p.list && (gridDim.x & 7u) == 0u) wg = (int64_t)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     // The first 128 frames of a pixel are gathered up front (two loads in flight), its decided rounds and their
     // bounds come with them (lane r holds round r), the weights of those frames sit in registers.
-    constexpr int PF = 2;
+    static_assert(PF == 2 || GROUP == 4, "deep register prefetch is for the whole-tile replays");
     const bool dense = p.list == nullptr;
-    float wreg[PF] = {0.0f, 0.0f};
+    float wreg[PF] = {};
     if constexpr (W) {
 #pragma unroll
         for (int c = 0; c < PF; c++) wreg[c] = c * 64 + lane < N ? p.weights[c * 64 + lane] : 0.0f;
@@ -687,7 +693,17 @@ int coop_group(const StackArgs &args)
 template <bool WINSOR, bool W>
 static hipError_t launch_coop(const StackArgs &args, int grid, size_t lds, hipStream_t stream, const char **name)
 {
-    if (coop_group(args) == 4) {
+    // (measured, profiles/r05_wsigma512_pf8_*, r05_wwinsor512_*: with PF = 8 a weighted sigma replay of 512 frames fetches
+    // 1.45 x the algorithmic bytes instead of 13.7 x and takes 35.8 instead of 34.6 ms per 1024 x 4096 pixels -- it is bound by
+    // the issue of the partition passes, not by its fetches; the winsorized replay, whose loops wait on memory between
+    // their chains, gains 10 - 12 %: 40.5 -> 36.5 ms.  PF = 4 at 129 ... 256 frames lost 6 - 7 % in both modes.)
+    static const bool deep_on = [] { const char *e = getenv("NL_COOP_PF"); return !(e && e[0] == '0'); }();      // NL_COOP_PF=0: two chunks at every depth (A/B)
+    static const bool deep_all = [] { const char *e = getenv("NL_COOP_PF"); return e && e[0] == '2'; }();       // NL_COOP_PF=2: plain sigma too
+    if (coop_group(args) == 4 && deep_on && (WINSOR || deep_all) && args.n_frames > 256 && args.n_frames <= 512) {
+        *name = WINSOR ? (W ? "stack_sigma_coop_kernel<true, true, 4, 8>" : "stack_sigma_coop_kernel<true, false, 4, 8>")
+                       : (W ? "stack_sigma_coop_kernel<false, true, 4, 8>" : "stack_sigma_coop_kernel<false, false, 4, 8>");
+        hipLaunchKernelGGL((stack_sigma_coop_kernel<WINSOR, W, 4, 8>), dim3(grid), dim3(64), lds, stream, args);
+    } else if (coop_group(args) == 4) {
         *name = WINSOR ? (W ? "stack_sigma_coop_kernel<true, true, 4>" : "stack_sigma_coop_kernel<true, false, 4>")
                        : (W ? "stack_sigma_coop_kernel<false, true, 4>" : "stack_sigma_coop_kernel<false, false, 4>");
         hipLaunchKernelGGL((stack_sigma_coop_kernel<WINSOR, W, 4>), dim3(grid), dim3(64), lds, stream, args);

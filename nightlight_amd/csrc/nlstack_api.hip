@@ -16,6 +16,17 @@
 
 #include "stack_kernels.h"
 
+// Kernels and pass protocols that were built, tested and measured slower than what is dispatched live in the
+// experiments build (make EXPERIMENTS=1, -DNL_EXPERIMENTS): the four-pixels-per-wave replay (stack_exact_coop4.hip),
+// chunked passes, the split / persistent LDS-column pass, the round-1 multi-lane kernel, the guarded linear fit.
+#ifdef NL_EXPERIMENTS
+#define NL_COOP4_SUPPORTED(mode, weighted, n) (nl::coop4_supported(mode, weighted, n) != 0)
+#define NL_LAUNCH_COOP4(...) nl::launch_stack_sigma_coop4(__VA_ARGS__)
+#else
+#define NL_COOP4_SUPPORTED(mode, weighted, n) false
+#define NL_LAUNCH_COOP4(...) hipErrorNotSupported
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -308,7 +319,14 @@ extern "C" {
 
 const char *nl_last_error(void) { return g_err.c_str(); }
 
-const char *nl_version(void) { return "nlstack 0.1.0 (gfx950)"; }
+const char *nl_version(void)
+{
+#ifdef NL_EXPERIMENTS
+    return "nlstack 0.1.0 (gfx950) +experiments";
+#else
+    return "nlstack 0.1.0 (gfx950)";
+#endif
+}
 
 void nl_release_cached_memory(void) { cache_release_all(); }
 
@@ -791,6 +809,9 @@ static bool linfit_guard_bufs(nl_stack_t *h, nl::LinfitGuardBufs *out)
 // (sigma 512 x 4096^2 10.72 against 10.20 ms); NL_MLZ_SPLIT=1 or developer switch 1024 turn it on.
 static void set_split_cols(nl_stack *h, int mode, int n_frames, nl::FastArgs &f)
 {
+#ifndef NL_EXPERIMENTS
+    (void)h; (void)mode; (void)n_frames; (void)f;          // (the default library carries the one-kernel pass only)
+#else
     const int rows = nl::mlz_split_rows(mode, n_frames);
     static const bool on = [] { const char *e = getenv("NL_MLZ_SPLIT"); return e && e[0] == '1'; }();
     // (the same class as persistent workgroups -- three per CU, no barrier, the rounds of a block behind the sorting of the
@@ -813,6 +834,7 @@ static void set_split_cols(nl_stack *h, int mode, int n_frames, nl::FastArgs &f)
     if (!h->d_cols) return;
     f.cols = h->d_cols;
     f.cols_stride = h->cols_stride;
+#endif
 }
 
 static bool ensure_bounds(nl_stack *h)
@@ -847,6 +869,7 @@ struct ChunkPlan {
 static void chunk_plan(const nl_stack *h, int mode, bool weighted, int n_frames, ChunkPlan *plan)
 {
     plan->n = 0;
+#ifdef NL_EXPERIMENTS
     // NL_CHUNKS (developer switch): "0" = never, "p1,p2,..." = these ranges whenever the fast path runs
     static const std::vector<double> env_plan = [] {
         std::vector<double> v;
@@ -888,8 +911,12 @@ static void chunk_plan(const nl_stack *h, int mode, bool weighted, int n_frames,
     }
     if (plan->n > 0 && at < h->npix) plan->len[plan->n - 1] += h->npix - at;
     if (plan->n < 2) plan->n = 0;
+#else
+    (void)h; (void)mode; (void)weighted; (void)n_frames;      // (the default library has no chunked passes: measured slower)
+#endif
 }
 
+#ifdef NL_EXPERIMENTS
 static int ensure_chunk_resources(nl_stack *h)
 {
     if (h->d_chunk_counts) return NL_OK;
@@ -906,6 +933,7 @@ static int ensure_chunk_resources(nl_stack *h)
     NL_HIP(dev_malloc(&h->d_chunk_counts, sizeof(unsigned) * 4 * kMaxChunks));
     return NL_OK;
 }
+#endif  // NL_EXPERIMENTS
 
 static int auto_select_mode(int l)   // stack.go:45-55
 {
@@ -1159,6 +1187,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
         NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
         h->last_has_counters = true;
         h->last_used_fast = true;
+#ifdef NL_EXPERIMENTS
     } else if (chunked) {
         // the sigma / winsorized fast path as a chunked pass (see chunk_plan): plain protocol (the memset above,
         // sharded clip counters, a reduction kernel at the end), one set of list lengths per chunk
@@ -1167,7 +1196,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
         NL_HIP(hipMemsetAsync(h->d_chunk_counts, 0, sizeof(unsigned) * 4 * kMaxChunks, h->stream));
         const bool record = mode == NL_ST_WINSOR_SIGMA && a.n_frames > 128 && fused_on && ensure_bounds(h);     // (as the unchunked pass below)
         static const bool coop4_env = [] { const char *e = getenv("NL_COOP4"); return e && e[0] == '1'; }();
-        const bool coop4 = coop4_env && nl::coop4_supported(mode, weighted, a.n_frames) != 0;
+        const bool coop4 = coop4_env && NL_COOP4_SUPPORTED(mode, weighted, a.n_frames);
         struct Fork { nl_stack *h; nl::StackArgs e; int mode; int grid0; bool coop4; hipEvent_t done; hipError_t err; };
         for (int k = 0; k < plan.n; k++) {
             const int64_t off = plan.off[k], len = plan.len[k];
@@ -1217,7 +1246,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
                 nl::StackArgs first = fk->e;
                 first.list_snap = const_cast<unsigned *>(fk->e.list_count) + 2;
                 first.list_part = 0;
-                if (err == hipSuccess) err = fk->coop4 ? nl::launch_stack_sigma_coop4(fk->mode, first, fk->grid0, hh->chunk_stream[1], &ignored)
+                if (err == hipSuccess) err = fk->coop4 ? NL_LAUNCH_COOP4(fk->mode, first, fk->grid0, hh->chunk_stream[1], &ignored)
                                                        : nl::launch_stack_sigma_coop(fk->mode, first, fk->grid0, hh->chunk_stream[1], &ignored);
                 if (err == hipSuccess) err = hipStreamWaitEvent(hh->chunk_stream[0], fk->done, 0);
                 fk->err = err;
@@ -1232,7 +1261,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
             const char *exact_name = "";
             e.list_snap = cc + 2;                         // the generic pass's additions
             e.list_part = 1;
-            if (coop4) NL_HIP(nl::launch_stack_sigma_coop4(mode, e, grid1, h->chunk_stream[0], &exact_name));
+            if (coop4) NL_HIP(NL_LAUNCH_COOP4(mode, e, grid1, h->chunk_stream[0], &exact_name));
             else       NL_HIP(nl::launch_stack_sigma_coop(mode, e, grid1, h->chunk_stream[0], &exact_name));
         }
         for (int i = 0; i < 2; i++) {
@@ -1244,6 +1273,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
         h->last_fused = false;
         h->last_has_counters = true;
         h->last_used_fast = true;
+#endif  // NL_EXPERIMENTS
     } else if (!h->force_exact && h->d_fb_list &&
                (nl::fast_supported(mode, weighted, a.n_frames, a.npix) || nl::fast_ml_supported(mode, weighted, a.n_frames, a.npix))) {
         // register-resident fast kernel; pixels it cannot decide go to the exact kernel
@@ -1358,7 +1388,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
         // sequential sums cost a third of the instructions, but with a quarter of the waves in flight the replay
         // turns latency-bound: C3 tile 5.32 -> 6.74 ms, sigma 512 tail 0.82 -> 1.45 ms -- measured, off by default
         static const bool coop4_env = [] { const char *e = getenv("NL_COOP4"); return e && e[0] == '1'; }();
-        const bool coop4 = coop && coop4_env && nl::coop4_supported(mode, weighted, a.n_frames) != 0;
+        const bool coop4 = coop && coop4_env && NL_COOP4_SUPPORTED(mode, weighted, a.n_frames);
         if (coop4) { grid0 = (grid0 + 3) / 4; grid1 = (grid1 + 3) / 4; }
         struct Fork { nl_stack *h; nl::StackArgs e; int mode; unsigned *snap; int grid0; bool coop4; bool cascade; hipError_t err; } fork{h, e, mode, snap, grid0, coop4, cascade, hipSuccess};
         nl::AfterDominant after = nullptr;
@@ -1375,7 +1405,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
                 nl::StackArgs first = k->e;
                 first.list_snap = k->snap;
                 first.list_part = 0;
-                if (err == hipSuccess) err = k->coop4 ? nl::launch_stack_sigma_coop4(k->mode, first, k->grid0, hh->stream, &ignored)
+                if (err == hipSuccess) err = k->coop4 ? NL_LAUNCH_COOP4(k->mode, first, k->grid0, hh->stream, &ignored)
                                                       : nl::launch_stack_sigma_coop(k->mode, first, k->grid0, hh->stream, &ignored);
                 if (err == hipSuccess) err = hipEventRecord(hh->ev_join, hh->stream);
                 k->err = err;
@@ -1385,7 +1415,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
             nl::StackArgs first = k->e;
             first.list_snap = k->snap;                    // the list as the dominant kernel left it (snapshot on the device)
             first.list_part = 0;
-            if (err == hipSuccess) err = k->coop4 ? nl::launch_stack_sigma_coop4(k->mode, first, k->grid0, hh->side_stream, &ignored)
+            if (err == hipSuccess) err = k->coop4 ? NL_LAUNCH_COOP4(k->mode, first, k->grid0, hh->side_stream, &ignored)
                                                   : nl::launch_stack_sigma_coop(k->mode, first, k->grid0, hh->side_stream, &ignored);
             if (err == hipSuccess) err = hipEventRecord(hh->ev_join, hh->side_stream);
             k->err = err;
@@ -1401,7 +1431,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
         if (coop) {
             e.list_snap = snap;                           // the generic pass's additions
             e.list_part = 1;
-            if (coop4) NL_HIP(nl::launch_stack_sigma_coop4(mode, e, grid1, h->stream, &exact_name));
+            if (coop4) NL_HIP(NL_LAUNCH_COOP4(mode, e, grid1, h->stream, &exact_name));
             else       NL_HIP(nl::launch_stack_sigma_coop(mode, e, grid1, h->stream, &exact_name));
             NL_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         } else {
@@ -1439,11 +1469,11 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
         NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
         NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
         h->last_has_counters = true;
-    } else if ((h->exact_flavour == 4 ||
+    } else if (NL_COOP4_SUPPORTED(mode, weighted, a.n_frames) &&           // (experiments build only)
+               (h->exact_flavour == 4 ||
                 (!h->force_exact && weighted && !(h->dev_flags & 8u) && mode == NL_ST_WINSOR_SIGMA &&
                  a.n_frames >= nl::kCoop4MinFrames && a.n_frames <= nl::kCoop4MaxFrames &&
-                 !(nl::decide_ml_supported(mode, a.n_frames, a.npix) && ensure_bounds(h)))) &&      // (only without a decision pass)
-               nl::coop4_supported(mode, weighted, a.n_frames)) {
+                 !(nl::decide_ml_supported(mode, a.n_frames, a.npix) && ensure_bounds(h))))) {      // (only without a decision pass)
         // the four-pixels-per-wave replay over the whole tile: weighted stacks of medium depth (the sequential sums
         // are a large share of a dense replay, and a row of 16 lanes wastes fewer of them on short ranges);
         // nl_stack_set_exact(h, 4) forces it (verification)
@@ -1456,7 +1486,8 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
             NL_HIP(nl::launch_stack_sigma_decide(a, h->stream, mode == NL_ST_WINSOR_SIGMA, &ignored));
         }
         const int g = dense_grid((a.npix + 3) / 4, 65536, h->width, 4);
-        NL_HIP(nl::launch_stack_sigma_coop4(mode, a, (int)g, h->stream, &h->last_kernel));
+        (void)g;
+        NL_HIP(NL_LAUNCH_COOP4(mode, a, (int)g, h->stream, &h->last_kernel));
         NL_HIP(hipEventRecord(h->ev_dom1, h->stream));
         NL_HIP(nl::launch_reduce_counters(h->d_partial, nl::kClipSlots, h->d_counters, h->stream));
         h->last_has_counters = true;

@@ -48,6 +48,8 @@ extern "C" int nl_debug_round_stats_ml(unsigned long long *out, int reset)
 #define NL_STAT(i, x) ((void)0)
 #endif
 
+#ifdef NL_EXPERIMENTS      // the round-1 kernel (zones in registers): superseded by the LDS-column kernels of stack_fast_mlz*.hip /
+                           // stack_fast_mlg.hip for every frame count 129 ... 512; kept for A/B runs (NL_MLZ=0, NL_MLG=0) in the experiments build
 template <int LPP, bool ZONAL, bool WINSOR, bool WIDE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZONAL ? (WINSOR ? 2 : 3) : 1, 8)))
 void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
@@ -431,6 +433,7 @@ void stack_sigma_ml_kernel(StackArgs p, FastArgs q)
         if (t_hi) atomicAdd(slot + 1, (unsigned long long)t_hi);
     }
 }
+#endif  // NL_EXPERIMENTS
 
 // StackMedian (stack.go:274-303) for 129..512 frames: the merged column gives the median
 // exactly (order independent); both middle ranks are looked up over whole lanes, so any
@@ -595,24 +598,30 @@ int fast_ml_supported(int mode, bool weighted, int n_frames, int64_t npix)
 // the nested launchers end in hipGetLastError(), which clears the pending error: keep the first one
 static inline void keep_first(hipError_t &acc, hipError_t e) { if (acc == hipSuccess) acc = e; }
 
+// Dominant kernel = the LDS-column kernel of the frame-count class (stack_fast_mlz*.hip), generic pass = whole columns in
+// LDS (stack_fast_mlg.hip).  The experiments build (make EXPERIMENTS=1) can put the round-1 register-zone kernel back
+// in either place: NL_MLZ=0 / NL_MLG=0.
 template <int LPP, bool WINSOR, bool WIDE>
 static hipError_t launch_ml(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
                             hipEvent_t dominant_done, AfterDominant after, void *user, const char **mlz_name, hipStream_t tail)
 {
     hipError_t err = hipSuccess;
-    const unsigned per_wg = 256 / LPP;
-    const unsigned tile_blocks = (unsigned)((args.npix + per_wg - 1) / per_wg);
     FastArgs f = fargs;
     f.in_list = nullptr;
     f.in_count = nullptr;
     f.in_capacity = 0;
-    if (!WIDE && mlz_name) {
-        // every position in use: the clipping rounds run on LDS columns (stack_fast_mlz.hip)
-        keep_first(err, launch_stack_sigma_mlz(args, f, stream, mlz_name, WINSOR));
-    } else {
+#ifdef NL_EXPERIMENTS
+    const unsigned per_wg = 256 / LPP;
+    const unsigned tile_blocks = (unsigned)((args.npix + per_wg - 1) / per_wg);
+    if (WIDE || !mlz_name) {
         hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, true, WINSOR, WIDE>), dim3(tile_blocks), dim3(256), 0, stream,
                            args, f);
         keep_first(err, hipGetLastError());
+    } else
+#endif
+    {
+        // every position in use: the clipping rounds run on LDS columns (stack_fast_mlz.hip)
+        keep_first(err, launch_stack_sigma_mlz(args, f, stream, mlz_name, WINSOR));
     }
     if (dominant_done) keep_first(err, hipEventRecord(dominant_done, stream));
     if (after) after(user);
@@ -620,17 +629,18 @@ static hipError_t launch_ml(const StackArgs &args, const FastArgs &fargs, hipStr
     f.in_list = fargs.gen_list;
     f.in_count = fargs.gen_count;
     f.in_capacity = fargs.gen_capacity;
-    // generic pass over the hand-over list: whole columns in LDS (stack_fast_mlg.hip); NL_MLG=0 (developer
-    // switch) keeps the register version, which masks every position of every lane in every round
+#ifdef NL_EXPERIMENTS
     static const bool mlg_on = [] { const char *e = getenv("NL_MLG"); return !(e && e[0] == '0'); }();
-    if (mlg_on) {
-        keep_first(err, launch_stack_sigma_mlg(args, f, generic_grid(fargs.gen_hint, 64 / LPP, 4 * kGenericGrid), stream, WINSOR));
+    if (!mlg_on) {
+        const unsigned gblocks = tile_blocks < kGenericGrid ? tile_blocks : kGenericGrid;
+        hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, false, WINSOR, false>), dim3(gblocks), dim3(256), 0, stream,
+                           args, f);
+        keep_first(err, hipGetLastError());
         return err;
     }
-    const unsigned gblocks = tile_blocks < kGenericGrid ? tile_blocks : kGenericGrid;
-    hipLaunchKernelGGL((stack_sigma_ml_kernel<LPP, false, WINSOR, false>), dim3(gblocks), dim3(256), 0, stream,
-                       args, f);
-    keep_first(err, hipGetLastError());
+#endif
+    // generic pass over the hand-over list: whole columns in LDS (stack_fast_mlg.hip)
+    keep_first(err, launch_stack_sigma_mlg(args, f, generic_grid(fargs.gen_hint, 64 / LPP, 4 * kGenericGrid), stream, WINSOR));
     return err;
 }
 
@@ -638,10 +648,12 @@ template <int LPP>
 static hipError_t launch_ml_variant(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name,
                               hipEvent_t dominant_done, bool winsor, AfterDominant after, void *user, hipStream_t tail)
 {
+    const int n = args.n_frames;
+#ifdef NL_EXPERIMENTS
     // tight zones when (almost) every position is used, otherwise the wide variant while the
     // last lane with samples holds more than 8 of them; in the few remaining cases the tight
     // variant hands every pixel to the generic pass
-    const int n = args.n_frames, nt = LPP * kMlNS;
+    const int nt = LPP * kMlNS;
     const bool wide = n < nt - 8 && n > ((n - 1) / kMlNS) * kMlNS + 8;
     static const std::string names[4] = {
         "stack_sigma_ml_kernel<" + std::to_string(LPP) + ", true, false, false>",
@@ -649,19 +661,21 @@ static hipError_t launch_ml_variant(const StackArgs &args, const FastArgs &fargs
         "stack_sigma_ml_kernel<" + std::to_string(LPP) + ", true, true, false>",
         "stack_sigma_ml_kernel<" + std::to_string(LPP) + ", true, true, true>"};
     *name = names[(winsor ? 2 : 0) + (wide ? 1 : 0)].c_str();
-    // NL_MLZ=0 (developer switch) keeps the register-zone kernel for A/B measurements
     static const bool mlz_on = [] { const char *e = getenv("NL_MLZ"); return !(e && e[0] == '0'); }();
-    const char **mlz_name = (mlz_on && fast_mlz_supported(winsor ? NL_ST_WINSOR_SIGMA : NL_ST_SIGMA, false, n)) ? name : nullptr;
-    if (mlz_name) {            // every frame count 129..512: LDS-column kernel of its class (stack_fast_mlz.hip)
-        if (winsor) return launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user, mlz_name, tail);
-        return launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user, mlz_name, tail);
+    if (!(mlz_on && fast_mlz_supported(winsor ? NL_ST_WINSOR_SIGMA : NL_ST_SIGMA, false, n))) {
+        if (winsor) {
+            if (wide) return launch_ml<LPP, true, true>(args, fargs, stream, dominant_done, after, user, nullptr, tail);
+            return launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user, nullptr, tail);
+        }
+        if (wide) return launch_ml<LPP, false, true>(args, fargs, stream, dominant_done, after, user, nullptr, tail);
+        return launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user, nullptr, tail);
     }
-    if (winsor) {
-        if (wide) return launch_ml<LPP, true, true>(args, fargs, stream, dominant_done, after, user, nullptr, tail);
-        return launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user, nullptr, tail);
-    }
-    if (wide) return launch_ml<LPP, false, true>(args, fargs, stream, dominant_done, after, user, nullptr, tail);
-    return launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user, nullptr, tail);
+#else
+    (void)n;
+#endif
+    // every frame count 129..512: LDS-column kernel of its class (stack_fast_mlz.hip), which sets *name
+    if (winsor) return launch_ml<LPP, true, false>(args, fargs, stream, dominant_done, after, user, name, tail);
+    return launch_ml<LPP, false, false>(args, fargs, stream, dominant_done, after, user, name, tail);
 }
 
 // kernel names as rocprofv3 prints them (template arguments: LPP, ZONAL, WINSOR, WIDE)

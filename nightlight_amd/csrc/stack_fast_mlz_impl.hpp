@@ -1079,6 +1079,8 @@ static bool launch_mlz_classes(int ntop, bool winsor, const StackArgs &args, con
         if (winsor) hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, true, NTOP>), dim3((unsigned)((args.npix + LW::PW - 1) / LW::PW)), dim3(LW::BLOCK), 0, stream, args, f);
         else if constexpr (L::SELECT) {
             const dim3 grid((unsigned)((args.npix + L::PW - 1) / L::PW));
+#ifdef NL_EXPERIMENTS
+            // (both measured slower than the one-kernel pass, DESIGN.md section 5n: instantiated in the experiments build only)
             if (f.cols) {
                 // split pass: the sorting kernel's workgroups retire as a whole (in the one-kernel pass three of a
                 // workgroup's four wave slots idle while its fourth wave runs the rounds), then one wave per 64 pixels
@@ -1094,7 +1096,9 @@ static bool launch_mlz_classes(int ntop, bool winsor, const StackArgs &args, con
                 static const int per_cu = [] { const char *e = getenv("NL_MLZ_WGS_PER_CU"); const int v = e ? atoi(e) : 3; return v >= 1 && v <= 8 ? v : 3; }();      // (experiments)
                 const unsigned wgs = (unsigned)(per_cu * cus);
                 hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, false, NTOP, 3>), dim3(grid.x < wgs ? grid.x : wgs), dim3(L::BLOCK), 0, stream, args, f);
-            } else {
+            } else
+#endif
+            {
                 hipLaunchKernelGGL((stack_sigma_mlz_kernel<LPP, false, NTOP>), grid, dim3(L::BLOCK), 0, stream, args, f);
             }
         }

@@ -207,7 +207,7 @@ def test_wave_per_pixel_exact_replay_is_bit_exact(nl, oracle, n):
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 7, 15, 16, 17, 33, 64, 65, 128, 130, 300, 512])
-def test_four_pixels_per_wave_exact_replay_is_bit_exact(nl, oracle, n):
+def test_four_pixels_per_wave_exact_replay_is_bit_exact(nl, oracle, experiments, n):
     # stack_exact_coop4.hip: the same replay with four pixels per wave on 16-lane rows (row_shr chains); forced
     # for every pixel (37 x 5 = 185 pixels: the last wave holds one pixel, rows with different sample counts,
     # NaN borders, ties)
@@ -762,7 +762,7 @@ def test_developer_switches_do_not_change_results(nl, oracle, mode, n, weighted)
 
 
 @pytest.mark.parametrize("n,weighted,height", [(512, False, 12), (500, False, 9), (512, True, 6)])
-def test_split_lds_column_pass_gives_the_bits_of_the_one_kernel_pass(nl, oracle, n, weighted, height):
+def test_split_lds_column_pass_gives_the_bits_of_the_one_kernel_pass(nl, oracle, experiments, n, weighted, height):
     # developer switch 1024: the selected LDS-column kernel (497 ... 512 frames, plain sigma) as a sorting kernel plus a
     # rounds kernel over columns kept in device memory (FastArgs::cols); 2048: as persistent workgroups that loop over
     # blocks of 64 pixels without a barrier -- same code for the rounds, so the same bits, counters and hand-over lists;

@@ -23,11 +23,16 @@ Prints ONE JSON line on rank 0 (contract in the task description) including
                strip of the same stack: 1 warm-up + median of 3, N separately
                allocated host frames, all host threads.
   also         the other stack depths of the north star (sigma clipping, 32 and 512 frames) and, on one GPU,
-               the remaining BASELINE.json configurations (C3 tile with its goal-seek, C4, C5) plus winsorized and
-               weighted sigma clipping at 128 frames: same protocol, each with the dominant kernel's fraction, the
-               pass's fraction and a parity flag (a strip of the same stack through the C ABI against the oracle).
+               the remaining BASELINE.json configurations (C3 tile with its goal-seek, C4, C5), winsorized and
+               weighted sigma clipping at 128 frames and what the reference's auto mode picks (winsorized 16 / 24
+               frames, linear fit 32 frames): same protocol, each with the dominant kernel's fraction, the pass's
+               fraction, the measured HBM traffic where the workload was profiled, and a parity flag (a strip of the
+               same stack through the C ABI against the oracle).
   fresh_handle what ONE OpStack.Apply pays on a new handle (stack.go:131-138: the drop-in creates a handle per Apply):
-               create, first pass without the hints a previous pass leaves, destroy -- wall-clock milliseconds.
+               create, first pass, destroy -- wall-clock milliseconds; with the grid hints the library carries over from
+               the last handle of the geometry, and ("without_inherited_hints") without them; a winsorized and a weighted
+               pass on the same frames as well (their scratch goes through the same buffer cache).
+  ranks        (--gpus N) every rank's wall clock per step, pass and dominant-kernel GPU time, and their min / max.
 """
 import argparse
 import json
@@ -43,7 +48,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MODE_NAMES = {0: "median", 1: "mean", 2: "sigma-clip", 3: "winsorized sigma-clip",
               4: "MAD sigma-clip", 5: "linear-fit"}
-TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
+TRAFFIC_FILES = ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
 
 
 def parse():
@@ -135,19 +140,20 @@ def cpu_baseline(st, args, rows, weights=None, frames_n=None, mode=None, width=N
                       % (rows, w, n, MODE_NAMES[mode], dt, threads, physical, model)}, res, (cl, ch)
 
 
-def measured_traffic(kernel, args, rows):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this command
+def measured_traffic(kernel, frames, width, rows, mode):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
     (profiles/rNN_traffic.json: FETCH_SIZE / WRITE_SIZE with the guide's gfx950
-    corrections), or (None, None) when this workload was not profiled."""
+    corrections; newest round first), or (None, None) when this workload -- this kernel at
+    this geometry -- was not profiled."""
     for name in TRAFFIC_FILES:
         try:
             doc = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
             continue
         for e in doc.get("entries", []):
-            if (e["kernel"] == kernel and e["frames"] == args.frames and e["width"] == args.width
-                    and e["rows"] == rows and e["mode"] == args.mode):
-                return e["traffic_bytes"], "profiles/%s (separate rocprofv3 --pmc passes of this command)" % name
+            if (e["kernel"] == kernel and e["frames"] == frames and e["width"] == width
+                    and e["rows"] == rows and e["mode"] == mode and e.get("traffic_bytes")):
+                return e["traffic_bytes"], "profiles/%s (separate rocprofv3 --pmc passes of this workload)" % name
     return None, None
 
 
@@ -276,9 +282,19 @@ def main():
         st.run_async(mode, args.kappa, args.kappa, 0.0)
         cl, ch = st.finish()
         sync_ms = (time.perf_counter() - t1) * 1e3
+        ranks = None
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_device else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            # every rank's own clock and GPU times, so that a straggler shows in the scaling record
+            mine = torch.tensor([dt, pass_ms, k_ms], dtype=torch.float64, device="cuda" if on_device else "cpu")
+            every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(every, mine)
+            rows_ = [[float(x) for x in e.tolist()] for e in every]
+            ranks = {"wall_ms_per_step": [round(r[0] * 1e3 / steps, 4) for r in rows_],
+                     "pass_ms": [round(r[1], 4) for r in rows_], "kernel_ms": [round(r[2], 4) for r in rows_],
+                     "pass_ms_min": round(min(r[1] for r in rows_), 4), "pass_ms_max": round(max(r[1] for r in rows_), 4),
+                     "kernel_ms_min": round(min(r[2] for r in rows_), 4), "kernel_ms_max": round(max(r[2] for r in rows_), 4)}
             dt = float(t.item())
             if on_device:
                 st.copy_counters_async(totals.data_ptr())
@@ -287,7 +303,7 @@ def main():
                 totals.copy_(torch.tensor([cl, ch], dtype=torch.int64))
             dist.all_reduce(totals)
             cl, ch = int(totals[0].item()), int(totals[1].item())
-        return st, {"dt": dt, "pass_ms": pass_ms, "k_ms": k_ms, "timed": timed, "cl": cl, "ch": ch, "sync_ms": sync_ms}
+        return st, {"dt": dt, "pass_ms": pass_ms, "k_ms": k_ms, "timed": timed, "cl": cl, "ch": ch, "sync_ms": sync_ms, "ranks": ranks}
 
     def strip_parity(frames, mode, geo, weights_, strip_rows, res, cc):
         """The first strip_rows rows of the tile through the C ABI against the oracle's result `res` / counters `cc`
@@ -310,10 +326,13 @@ def main():
                 "bit_exact": bool(np.array_equal(got, res, equal_nan=True)),
                 "within_1e-5": bool(same_nan and rel <= 1e-5)}
 
-    def fresh_handle_cost(st, frames, mode, weights_):
+    def fresh_handle_cost(st, frames, mode, weights_, no_hints=False):
         """What ONE Apply pays on a new handle (the drop-in creates a handle per Apply, go/stackhip/stack_hip.go): create
-        (device buffers, streams, events), the first pass -- no grid hints from a previous pass, lazily allocated
-        scratch -- and destroy; the frames are the resident ones of `st` (attached, not uploaded again)."""
+        (device buffers, streams, events), the first pass and destroy; the frames are the resident ones of `st` (attached,
+        not uploaded again).  The first pass of a handle has no list lengths of its own to size its replay grids with; the
+        library remembers those of the last handle of the same geometry in the process (hints_load / hints_store,
+        nlstack_api.hip), so "warm" numbers are WITH those inherited hints and the fused protocol they allow;
+        no_hints=True (developer switch 512) times a first pass without them, as the first Apply of a process runs."""
         def cycle():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -321,6 +340,8 @@ def main():
             t1 = time.perf_counter()
             h2.attach_device_frames(st.frames_device_ptr())
             h2.set_weights(weights_)
+            if no_hints:
+                h2.set_dev_flags(512)
             t2 = time.perf_counter()
             h2.run_async(mode, args.kappa, args.kappa, 0.0)
             cl2, ch2 = h2.finish()
@@ -342,8 +363,13 @@ def main():
                 "clip_counters": [warm[4], warm[5]],
                 "note": "one handle per OpStack.Apply: create + first pass + destroy on frames already resident "
                         "(uploads excluded); the library parks the large buffers of a destroyed handle for the next one "
-                        "of the same geometry; the timed steps above re-use one handle"}
+                        "of the same geometry and hands its list lengths on as grid hints"
+                        + (" -- here the first pass ran WITHOUT inherited hints (developer switch 512)" if no_hints else
+                           " -- the first pass ran WITH the hints the previous handle left") +
+                        "; the timed steps above re-use one handle"}
 
+    default_workload_early = (args.frames == 128 and args.mode == 2 and args.width == 4096 and args.height == 4096 and
+                              not args.weak and not args.weighted and not args.image_height)
     weights = None
     if args.weighted:
         weights = np.array([0.2 + 0.8 * ((k * 37) % 101) / 100.0 for k in range(n)], np.float32)
@@ -356,7 +382,7 @@ def main():
         value = pixels_per_step * args.steps / dt / 1e6
         alg_bytes = 4.0 * rows * w * (n + 1)          # per launch (rank 0's tile), SURVEY 8d
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic, traffic_source = measured_traffic(st.last_kernel_name, args, rows)
+        traffic, traffic_source = measured_traffic(st.last_kernel_name, n, w, rows, args.mode)
         if args.weak:
             workload = "%d x %dx%d fp32 frames per GPU (weak scaling), %s%s kappa=%g, frames resident in HBM" % (
                 n, rows, w, MODE_NAMES[args.mode], " (weighted)" if args.weighted else "", args.kappa)
@@ -390,6 +416,8 @@ def main():
             # this is one pass run the way OpStack.Apply runs it: enqueue, wait, read the counters back
             "ms_per_step_synchronous": round(tm["sync_ms"], 4),
         }
+        if tm["ranks"] is not None:
+            out["ranks"] = tm["ranks"]            # per rank: wall clock per step, pass and dominant-kernel GPU time (HIP events)
         if world == 1 and not args.no_cpu:
             cpu_rows = args.cpu_rows
             if cpu_rows <= 0:
@@ -403,6 +431,16 @@ def main():
             out["cpu_baseline"] = base
         if world == 1 and dist is None:
             out["fresh_handle"] = fresh_handle_cost(st, n, args.mode, weights)
+            out["fresh_handle"]["without_inherited_hints"] = {
+                k: v for k, v in fresh_handle_cost(st, n, args.mode, weights, no_hints=True).items()
+                if k in ("ms_create", "ms_first_pass_fresh_handle", "ms_second_pass_synchronous", "ms_destroy", "note")}
+            if default_workload_early:
+                # the scratch of the other pass protocols goes through the same buffer cache: a winsorized stack (the
+                # cascade's lists) and a weighted one (the decision pass's thresholds) on the same resident frames
+                w_ = np.array([0.2 + 0.8 * ((k * 37) % 101) / 100.0 for k in range(n)], np.float32)
+                for tag, m_, wt_ in (("winsorized", 3, None), ("weighted_sigma", 2, w_)):
+                    c = fresh_handle_cost(st, n, m_, wt_)
+                    out["fresh_handle"][tag] = {k: c[k] for k in ("ms_create", "ms_first_pass_fresh_handle", "ms_destroy", "ms_create_destroy")}
 
     st.close()
     # The other stack depths the north star names (4096 x 4096 x {32, 512} fp32, sigma clipping), same protocol
@@ -422,7 +460,12 @@ def main():
                        ("C4", 128, 5, None, None, False),
                        ("C5", 64, 0, None, (6000, 4000, 0, 4000), False),
                        ("winsor128", 128, 3, None, None, False),
-                       ("weighted sigma128", 128, 2, w128, None, False)]
+                       ("weighted sigma128", 128, 2, w128, None, False),
+                       # what the reference's auto mode (-stMode 6, stack.go:45-55) picks for 15 ... 24 frames (winsorized
+                       # clipping) and from 25 frames on (linear fit)
+                       ("winsor16", 16, 3, None, None, False),
+                       ("winsor24", 24, 3, None, None, False),
+                       ("linfit32", 32, 5, None, None, False)]
         also = []
         for tag, frames, mode, wts, geo, goal_seek in extras:
             st2, t2 = time_stack(frames, mode, args.steps, args.warmup, wts, geo)
@@ -441,9 +484,15 @@ def main():
                      "pass_frac": round(alg / (t2["pass_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                      "algorithmic_bytes": alg, "clip_low": t2["cl"], "clip_high": t2["ch"],
                      "pixels_redone_by_exact_kernel": st2.last_fallback_pixels}
+                e["traffic"], e["traffic_source"] = measured_traffic(st2.last_kernel_name, frames, gw, grows, mode)
+                if t2["ranks"] is not None:
+                    e["ranks"] = t2["ranks"]
                 if mode == 5:
                     # (the linear fit is a cascade of stages: kernel_ms is its first stage, the pass is what counts)
                     e["note"] = "kernel_ms = first stage of the cascade (stack_linfit.hip); pass_ms covers all stages"
+                if mode == 3 and 12 <= frames <= 96:
+                    e["note"] = ("kernel_ms = first stage of the winsorization cascade (stack_fast_sigma_impl.hpp); its "
+                                 "continuation stages, the generic pass and the replays are in pass_ms")
                 if goal_seek:
                     t0 = time.perf_counter()
                     _, gcl, gch, gsl, gsh, gpasses = st2.find_sigmas(mode, 0.5, 0.5, fetch=False)

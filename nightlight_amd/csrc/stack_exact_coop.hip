@@ -704,12 +704,12 @@ static hipError_t launch_coop(const StackArgs &args, int grid, size_t lds, hipSt
                        : (W ? "stack_sigma_coop_kernel<false, true, 4, 8>" : "stack_sigma_coop_kernel<false, false, 4, 8>");
         hipLaunchKernelGGL((stack_sigma_coop_kernel<WINSOR, W, 4, 8>), dim3(grid), dim3(64), lds, stream, args);
     } else if (coop_group(args) == 4) {
-        *name = WINSOR ? (W ? "stack_sigma_coop_kernel<true, true, 4>" : "stack_sigma_coop_kernel<true, false, 4>")
-                       : (W ? "stack_sigma_coop_kernel<false, true, 4>" : "stack_sigma_coop_kernel<false, false, 4>");
+        *name = WINSOR ? (W ? "stack_sigma_coop_kernel<true, true, 4, 2>" : "stack_sigma_coop_kernel<true, false, 4, 2>")
+                       : (W ? "stack_sigma_coop_kernel<false, true, 4, 2>" : "stack_sigma_coop_kernel<false, false, 4, 2>");
         hipLaunchKernelGGL((stack_sigma_coop_kernel<WINSOR, W, 4>), dim3(grid), dim3(64), lds, stream, args);
     } else {
-        *name = WINSOR ? (W ? "stack_sigma_coop_kernel<true, true, 1>" : "stack_sigma_coop_kernel<true, false, 1>")
-                       : (W ? "stack_sigma_coop_kernel<false, true, 1>" : "stack_sigma_coop_kernel<false, false, 1>");
+        *name = WINSOR ? (W ? "stack_sigma_coop_kernel<true, true, 1, 2>" : "stack_sigma_coop_kernel<true, false, 1, 2>")
+                       : (W ? "stack_sigma_coop_kernel<false, true, 1, 2>" : "stack_sigma_coop_kernel<false, false, 1, 2>");
         hipLaunchKernelGGL((stack_sigma_coop_kernel<WINSOR, W, 1>), dim3(grid), dim3(64), lds, stream, args);
     }
     return hipGetLastError();

@@ -70,7 +70,7 @@ constexpr int kMaxChunks = 16;             // pixel ranges of a chunked pass
 // workgroup" for every stage (the last one runs to the end): measured on 4096^2 -- up to 40 frames
 // 16 / 24 frames 3.68 / 3.94 -> 2.97 / 3.07 ms, 41 ... 96 frames (64: 5.22 -> 4.59 ms); beyond that a continuing stage
 // re-reads every cache line of the stack for an eighth of its pixels and the cascade loses (128 frames: 5.43 -> 5.83 ms)
-constexpr const char *kWinsorPlanShallow = "1:6,1:12:4,2:16:4,0:0:4";   // (round 5, with the certificate: 1:8 -> 1:6, 16 frames 2.34 -> 2.18 ms)
+constexpr const char *kWinsorPlanShallow = "1:6,1:12:4,0:0:4";   // (round 5, with the certificate: first stage 8 -> 6 rounds, three stages instead of four: 16 / 24 / 32 frames 2.34 / 2.78 / 2.97 -> 2.17 / 2.71 / 2.80 ms)
 constexpr const char *kWinsorPlanDeep = "2:12,2:16:8,3:24:4,0:0:4";
 constexpr int kWinsorCascadeMaxFrames = 96;
 // per-pass device scratch, zeroed by one memset (or, in the fused protocol of the sigma / winsorized fast path, by

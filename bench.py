@@ -231,29 +231,40 @@ def main():
         if weights is not None:
             st.set_weights(weights)
         stream = torch.cuda.ExternalStream(st.stream_ptr, device=device) if (dist is not None and on_device) else None
-        pending = [None]
+        # Device-side reduction without a copy kernel: pass i leaves its counters in ring[i % 3] (the caller's buffer,
+        # nl_stack_set_counters_buffer), the all-reduce of pass i runs in place on its first two words while pass i + 1
+        # has the device, and a buffer is handed out again only behind the collective that used it last.
+        ring = torch.zeros((3, 4), dtype=torch.int64, device="cuda") if (dist is not None and on_device) else None
+        works = [None, None, None]
+        seq = [0]
 
         def step():
+            if dist is not None and on_device:
+                k = seq[0] % 3
+                if works[k] is not None:
+                    with torch.cuda.stream(stream):
+                        works[k].wait()                     # (three passes old: long done; orders the reuse of the buffer)
+                    works[k] = None
+                st.set_counters_buffer(ring[k].data_ptr())
             st.run_async(mode, args.kappa, args.kappa, 0.0)
             if dist is None:
                 return
             if on_device:
-                # device-side reduction on the handle's own stream; the all-reduce of pass i overlaps pass i+1
                 with torch.cuda.stream(stream):
-                    if pending[0] is not None:
-                        pending[0].wait()
-                    st.copy_counters_async(totals.data_ptr())
-                    pending[0] = dist.all_reduce(totals, async_op=True)
+                    works[seq[0] % 3] = dist.all_reduce(ring[seq[0] % 3][:2], async_op=True)
+                seq[0] += 1
             else:                                   # gloo rehearsal: counters through the host
                 cl, ch = st.finish()
                 totals.copy_(torch.tensor([cl, ch], dtype=torch.int64))
                 dist.all_reduce(totals)
 
         def fence():
-            if pending[0] is not None:
+            if stream is not None:
                 with torch.cuda.stream(stream):
-                    pending[0].wait()
-                pending[0] = None
+                    for k in range(3):
+                        if works[k] is not None:
+                            works[k].wait()
+                            works[k] = None
             st.finish()
             torch.cuda.synchronize()
             if dist is not None:
@@ -278,6 +289,8 @@ def main():
         pass_ms = float(np.mean([t[0] for t in times]))
         k_ms = float(np.mean([t[1] for t in times]))
         # one more pass, synchronous as OpStack.Apply runs it (enqueue, wait, read the counters back)
+        if ring is not None:
+            st.set_counters_buffer(None)                     # (back to the handle's own counters)
         t1 = time.perf_counter()
         st.run_async(mode, args.kappa, args.kappa, 0.0)
         cl, ch = st.finish()

@@ -194,6 +194,16 @@ void *nl_stack_counters_device_ptr(nl_stack_t *h);
 /* Enqueues, behind the last pass on the handle's stream, a copy of those 16 bytes into a
  * caller-owned device buffer (zeros for modes without counters). */
 int nl_stack_copy_counters_async(nl_stack_t *h, void *device_dst);
+/* The passes enqueued from now on leave their {clip_low, clip_high} (two int64; then two more 64-bit words of
+ * bookkeeping) in `device_buf` -- 32 bytes of device memory of the caller, on the handle's device -- instead of
+ * the handle's own buffer; NULL goes back to the own buffer.  For a per-process launcher that reduces the counters
+ * of every pass over the ranks on the device (RCCL, stack.go:193-198 is a mutex-protected sum over goroutines): with a
+ * small ring of buffers -- pass i into buffer i mod 3, the all-reduce of pass i in place on the first 16 bytes while
+ * pass i + 1 runs -- no copy kernel sits between a pass and its collective (bench.py; 11 us of a 0.27 ms pass on one of
+ * eight row tiles of the headline stack).  nl_stack_finish reads the buffer of the LAST pass, i.e. whatever the
+ * caller's collective has made of it by then.  A buffer must not be handed to a new pass before the collective of
+ * the pass that wrote it last has finished. */
+int nl_stack_set_counters_buffer(nl_stack_t *h, void *device_buf);
 /* on != 0: run every mode with the bit-exact kernels only (per-pixel replay
  * of the reference's permutation; slow, used for verification; 1 = one pixel
  * per lane with the column in LDS, 2 = one wavefront per pixel, 3 = one

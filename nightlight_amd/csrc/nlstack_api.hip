@@ -260,7 +260,8 @@ struct nl_stack {
     bool force_exact = false;
     int exact_flavour = 0;            // nl_stack_set_exact argument: 1 = LDS column kernel, 2 = wave-per-pixel replay
     bool last_used_fast = false;
-    unsigned long long *d_counters = nullptr;  // [2]
+    unsigned long long *d_counters = nullptr;  // [4]: where a pass leaves {clip_low, clip_high, list lengths, -}: the handle's own buffer or the caller's (nl_stack_set_counters_buffer)
+    unsigned long long *d_counters_own = nullptr;
     double *d_stat_partial = nullptr;          // [kStatBlocks*3]
     // linear-fit cascade (stack_linfit.hip): ping-pong pixel lists + liveness masks, lazily allocated
     // (a third list + masks for the guarded stages' hand-overs, stack_linfit_guard.hip: up to 128 frames)
@@ -363,7 +364,7 @@ static int destroy_impl(nl_stack_t *h)
     cached_free(h->d_fb_list, sizeof(unsigned) * (size_t)h->npix, h->device);
     cached_free(h->d_gen_list, sizeof(unsigned) * (size_t)h->npix, h->device);
     if (h->d_cols) cached_free(h->d_cols, h->cols_bytes, h->device);
-    if (h->d_counters) (void)hipFree(h->d_counters);
+    if (h->d_counters_own) (void)hipFree(h->d_counters_own);
     if (h->d_stat_partial) (void)hipFree(h->d_stat_partial);
     if (h->d_ingest) (void)hipFree(h->d_ingest);
     if (h->d_ingest_async) (void)hipFree(h->d_ingest_async);
@@ -434,7 +435,8 @@ static int create_impl(nl_stack_t *h)
         NL_HIP(cached_malloc((void **)&h->d_fb_list, sizeof(unsigned) * (size_t)h->npix, h->device));
         NL_HIP(cached_malloc((void **)&h->d_gen_list, sizeof(unsigned) * (size_t)h->npix, h->device));
     }
-    NL_HIP(dev_malloc(&h->d_counters, sizeof(unsigned long long) * 4));      // {clip_low, clip_high, list lengths (fused passes), -}
+    NL_HIP(dev_malloc(&h->d_counters_own, sizeof(unsigned long long) * 4));      // {clip_low, clip_high, list lengths (fused passes), -}
+    h->d_counters = h->d_counters_own;
     NL_HIP(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * 4, h->stream));
     NL_HIP(dev_malloc(&h->d_stat_partial, sizeof(double) * 3 * kStatBlocks));
 
@@ -1688,6 +1690,13 @@ int nl_stack_copy_counters_async(nl_stack_t *h, void *device_dst)
 
 void *nl_stack_stream(nl_stack_t *h) { return h ? (void *)h->stream : nullptr; }
 void *nl_stack_counters_device_ptr(nl_stack_t *h) { return h ? (void *)h->d_counters : nullptr; }
+
+int nl_stack_set_counters_buffer(nl_stack_t *h, void *device_buf)
+{
+    NL_CHECK_HANDLE(h);
+    h->d_counters = device_buf ? static_cast<unsigned long long *>(device_buf) : h->d_counters_own;
+    return NL_OK;
+}
 
 float nl_stack_last_kernel_ms(nl_stack_t *h)
 {

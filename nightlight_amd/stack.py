@@ -207,6 +207,10 @@ class StackHandle:
         """Enqueue a copy of the last pass's counters to a device buffer (2 x int64) on the handle's stream."""
         capi.check(self._lib.nl_stack_copy_counters_async(self._h, C.c_void_p(int(device_ptr))))
 
+    def set_counters_buffer(self, device_ptr):
+        """Passes enqueued from now on leave their counters in the caller's device buffer (32 bytes; None: the handle's own)."""
+        capi.check(self._lib.nl_stack_set_counters_buffer(self._h, C.c_void_p(int(device_ptr)) if device_ptr else None))
+
     @property
     def counters_device_ptr(self):
         """Device address of the last pass's {clip_low, clip_high} (2 x int64)."""

@@ -227,8 +227,30 @@ def _rccl_worker(_index, port, out_path):
     st.finish()
     torch.cuda.synchronize()
     seen.append(totals.clone())
+    # round 5, what bench.py does now: no copy kernel -- pass i leaves its counters in ring[i % 3] (the caller's buffer,
+    # nl_stack_set_counters_buffer), the all-reduce runs in place on it while pass i + 1 has the device, a buffer is
+    # handed out again behind the collective that used it last
+    ring = torch.zeros((3, 4), dtype=torch.int64, device="cuda")
+    works = [None, None, None]
+    for it in range(7):
+        k = it % 3
+        if works[k] is not None:
+            with torch.cuda.stream(stream):
+                works[k].wait()
+        st.set_counters_buffer(ring[k].data_ptr())
+        st.run_async(2, 2.5 + 0.25 * (it % 4), 2.5)
+        with torch.cuda.stream(stream):
+            works[k] = dist.all_reduce(ring[k][:2], async_op=True)
+    with torch.cuda.stream(stream):
+        for w_ in works:
+            w_.wait()
+    st.finish()
+    torch.cuda.synchronize()
+    ring_totals = ring[:, :2].cpu().numpy()                 # passes 6, 4, 5 (it = 6 -> k = 0, 4 -> 1, 5 -> 2)
+    st.set_counters_buffer(None)
+    own = st.run(2, 2.5, 2.5)[1:]
     np.savez(out_path, gs_res=gs[0], gs=np.array(gs[1:], np.float64), backend=np.array([dist.get_backend()]),
-             async_totals=np.stack([t.cpu().numpy() for t in seen]), **out)
+             async_totals=np.stack([t.cpu().numpy() for t in seen]), ring_totals=ring_totals, own_after=np.array(own), **out)
     sh.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -254,9 +276,15 @@ def test_rccl_world_size_one_runs_the_device_side_reduction(tmp_path, oracle, nl
     assert tuple(d["gs"][:2]) == (gcl, gch) and int(d["gs"][4]) == passes
     assert (np.float32(d["gs"][2]), np.float32(d["gs"][3])) == (gsl, gsh)
     # the asynchronous per-pass totals: pass i's counters, reduced while pass i+1 ran
+    want_by_it = {}
     for it in range(4):
         rc, _, wl, wh, _ = oracle.stack_apply(2, frames, None, 2.5 + 0.25 * it, 2.5)
+        want_by_it[it] = (wl, wh)
         assert tuple(int(x) for x in d["async_totals"][it]) == (wl, wh), it
+    # the ring protocol (nl_stack_set_counters_buffer): buffer k holds the totals of the last pass that wrote it
+    for k, it in ((0, 6), (1, 4), (2, 5)):
+        assert tuple(int(x) for x in d["ring_totals"][k]) == want_by_it[it % 4], (k, it)
+    assert tuple(int(x) for x in d["own_after"]) == want_by_it[0]            # back on the handle's own buffer
 
 
 def test_bench_force_dist_reports_the_rccl_protocol_on_one_gpu():

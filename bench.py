@@ -351,7 +351,7 @@ def main():
             t0 = time.perf_counter()
             h2 = StackHandle(frames, w, image_rows, row0=row0, rows=rows, device=device)
             t1 = time.perf_counter()
-            h2.attach_device_frames(st.frames_device_ptr())
+            h2.attach_device_frames(st.frames_device_ptr(), st.frame_stride())
             h2.set_weights(weights_)
             if no_hints:
                 h2.set_dev_flags(512)

@@ -98,7 +98,8 @@ int nl_stack_upload_tile(nl_stack_t *h, int idx, const float *host_tile);
 int nl_stack_upload_frame_async(nl_stack_t *h, int idx, const float *host_frame);
 int nl_stack_upload_wait(nl_stack_t *h);
 /* Device address of the planar frame buffer (for in-place producers that
- * already live on the GPU); valid until destroy/attach. */
+ * already live on the GPU); valid until destroy/attach.  Frame k starts at
+ * nl_stack_frame_stride(h) * k floats, see below. */
 void *nl_stack_frames_device_ptr(nl_stack_t *h);
 /* ---- FITS framing (host): where the payload sits in a file image, and the frame around a result ------------------
  * internal/fits/read.go:445-469 reads the header in 2880-byte units of 80-byte cards up to END; :97-147 take SIMPLE,
@@ -128,9 +129,19 @@ int64_t nl_fits_padded_bytes(int64_t payload_bytes);
  * weighted clip modes' decision pass).  The reference sizes its batches to host memory (stackbatches.go:121-187); a
  * caller doing the same for the device reads this.  No counterpart in the reference. */
 int64_t nl_stack_device_bytes(nl_stack_t *h);
-/* Lends an existing device buffer of the same layout instead of the owned
- * one (NULL restores the owned buffer).  The caller keeps it alive. */
+/* Lends an existing DENSE device buffer -- frame k at device_frames + k * rows * width floats -- instead of the
+ * owned one (NULL restores the owned buffer).  The caller keeps it alive. */
 int nl_stack_attach_device_frames(nl_stack_t *h, void *device_frames);
+/* Frame layout.  The owned buffer is planar with nl_stack_frame_stride(h) floats between consecutive frames:
+ * rows*width rounded up, plus a fixed padding, so that the same pixel of consecutive frames does not fall into the
+ * same HBM channel and bank (a power-of-two frame size such as 4096 x 4096 x 4 bytes otherwise costs the 512-frame
+ * pass 12 %).  Producers that write through nl_stack_frames_device_ptr, and handles that
+ * borrow another handle's frames, use this stride: frame k starts at ptr + k * stride floats.  The _strided attach
+ * lends a buffer of any stride >= rows*width (a multiple of 4 floats when rows*width is one); the plain attach above
+ * is the stride rows*width.  All upload / download / ingest / statistics entry points follow the handle's current
+ * stride.  No counterpart in the reference (its frames are separate Go slices). */
+int64_t nl_stack_frame_stride(nl_stack_t *h);
+int nl_stack_attach_device_frames_strided(nl_stack_t *h, void *device_frames, int64_t frame_stride);
 /* Fills all frames on the device with the deterministic synthetic stack of
  * SURVEY.md section 8d (sky gradient + per-frame gain/offset/noise, 0.4 % hot
  * and 0.1 % cold outliers, NaN borders, one all-NaN 8x8 patch).  Pixel

@@ -33,7 +33,7 @@ EXPORTS = [
     "nl_stack_create", "nl_stack_destroy",
     "nl_stack_upload_frame", "nl_stack_upload_tile", "nl_stack_upload_frame_async", "nl_stack_upload_wait", "nl_stack_frames_device_ptr", "nl_stack_device_bytes", "nl_release_cached_memory",
     "nl_fits_parse_header", "nl_fits_write_header", "nl_fits_padded_bytes",
-    "nl_stack_attach_device_frames", "nl_stack_fill_synthetic", "nl_stack_download_tile", "nl_stack_download_rows",
+    "nl_stack_attach_device_frames", "nl_stack_attach_device_frames_strided", "nl_stack_frame_stride", "nl_stack_fill_synthetic", "nl_stack_download_tile", "nl_stack_download_rows",
     "nl_stack_set_active_frames", "nl_stack_set_weights", "nl_weights_from_scalars",
     "nl_stack_linfit_stage_counts", "nl_stack_run", "nl_stack_run_async", "nl_stack_finish", "nl_stack_result_device_ptr",
     "nl_stack_last_mode", "nl_stack_last_kernel_ms", "nl_stack_last_dominant_kernel_ms",
@@ -113,6 +113,9 @@ def load():
     L.nl_fits_padded_bytes.argtypes = [C.c_int64]
     L.nl_fits_padded_bytes.restype = C.c_int64
     L.nl_stack_attach_device_frames.argtypes = [vp, vp]
+    L.nl_stack_attach_device_frames_strided.argtypes = [vp, vp, C.c_int64]
+    L.nl_stack_frame_stride.argtypes = [vp]
+    L.nl_stack_frame_stride.restype = C.c_int64
     L.nl_stack_fill_synthetic.argtypes = [vp, C.c_uint64]
     L.nl_stack_set_weights.argtypes = [vp, _f32p]
     L.nl_stack_set_active_frames.argtypes = [vp, C.c_int]

@@ -216,6 +216,8 @@ struct nl_stack {
     int n_frames = 0, width = 0, height = 0, row0 = 0, rows = 0;
     int n_capacity = 0;               // frame slots allocated; n_frames <= n_capacity are in use (nl_stack_set_active_frames)
     int64_t npix = 0;                 // rows*width
+    int64_t fstride = 0;              // floats between consecutive frames of the buffer d_frames points at
+    int64_t fstride_owned = 0;        // ... of the owned buffer (padded_frame_stride); a lent buffer brings its own
     hipStream_t stream = nullptr;
     // HIP events of the last kTimingRing passes (whole pass; dominant kernel only), so a caller can
     // queue many passes without a host sync and read every pass's GPU time afterwards
@@ -299,6 +301,34 @@ struct nl_stack {
     const char *last_kernel = "";
 };
 
+// Floats between consecutive frames of the owned planar buffer.  A stride that is a multiple of a large power of two
+// -- 4096 x 4096 floats = 2^26 bytes, or a 512-row tile's 2^23 -- puts the same pixel of every frame into the same
+// HBM channel / bank: the 4 frames one load of the LDS-column kernels reads, and the 128-512 loads a wave has in
+// flight, then queue on a few banks while the rest idle.  Measured on sigma 512 x 4096^2 (profiles/r05_stride_pad.txt):
+// stride + 0: 10.9 ms, + 16 KiB: 10.6, + 32 KiB: 10.2, + 64 KiB: 9.75, + 64 KiB + 256 B: 9.60, more: no further gain;
+// 32 frames are indifferent, 128 frames gain 1-3 %.  So the frame is rounded up to 128 KiB and 64 KiB + 256 B are added:
+// the residue of the stride modulo 128 KiB is the measured optimum for every tile size, at a cost of at most 192 KiB
+// per frame.  Small tiles (< 1 MiB per frame) are left dense.  NL_STRIDE_PAD=<floats> (developer) sets the padding
+// added to the tile's pixel count instead (0 = the dense layout of rounds 1-4).
+static bool frame_stride_addressable(int64_t npix, int64_t stride)
+{
+    // pixel offset + 3 frames in one signed 32-bit byte offset (multi-lane gathers), stride a multiple of 16 bytes
+    // where the dense layout is one (the float4 loads of the mean and the replay kernels)
+    return (npix + 3 * stride) * 4 < ((int64_t)1 << 31) && (npix % 4 != 0 || stride % 4 == 0);
+}
+
+static int64_t padded_frame_stride(int64_t npix)
+{
+    const char *e = getenv("NL_STRIDE_PAD");                  // read per handle: the tests switch it
+    const long env_pad = e ? atol(e) : -1L;
+    int64_t stride = npix;
+    if (env_pad >= 0) stride = npix + env_pad;
+    else if (npix >= (1 << 18)) stride = ((npix + 32767) & ~(int64_t)32767) + 16384 + 64;
+    if (stride != npix && npix < nl::kFastMaxPixels && !frame_stride_addressable(npix, stride)) stride = npix;
+    return stride;
+}
+
+
 // Grid of a dense replay whose workgroups stride through the pixels (item = workgroup + i * grid): with a grid that
 // is a multiple of the image width a workgroup would visit ONE image column throughout, and the few workgroups of the
 // alignment borders -- NaN columns, every pixel a full replay -- would run three times as long as the rest with the
@@ -353,7 +383,7 @@ static int destroy_impl(nl_stack_t *h)
     for (int i = 0; i < 2; i++)
         if (h->chunk_stream[i]) (void)hipStreamSynchronize(h->chunk_stream[i]);
     // (the large create-time buffers are parked for the next handle of the same geometry, see cached_free)
-    cached_free(h->d_frames_owned, (size_t)h->npix * sizeof(float) * (size_t)h->n_capacity, h->device);
+    cached_free(h->d_frames_owned, (size_t)h->fstride_owned * sizeof(float) * (size_t)h->n_capacity, h->device);
     cached_free(h->d_out, (size_t)h->npix * sizeof(float), h->device);
     if (h->d_acc) (void)hipFree(h->d_acc);
     if (h->d_weights) (void)hipFree(h->d_weights);
@@ -421,7 +451,8 @@ static int create_impl(nl_stack_t *h)
     NL_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     NL_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     const size_t frame_bytes = (size_t)h->npix * sizeof(float);
-    NL_HIP(cached_malloc((void **)&h->d_frames_owned, frame_bytes * (size_t)h->n_frames, h->device));
+    h->fstride = h->fstride_owned = padded_frame_stride(h->npix);
+    NL_HIP(cached_malloc((void **)&h->d_frames_owned, (size_t)h->fstride * sizeof(float) * (size_t)h->n_frames, h->device));
     h->d_frames = h->d_frames_owned;
     NL_HIP(cached_malloc((void **)&h->d_out, frame_bytes, h->device));
     NL_HIP(dev_malloc(&h->d_weights, sizeof(float) * (size_t)h->n_frames));
@@ -510,7 +541,7 @@ int nl_stack_upload_tile(nl_stack_t *h, int idx, const float *host_tile)
     NL_CHECK_HANDLE(h);
     if (idx < 0 || idx >= h->n_frames || !host_tile)
         return fail(NL_ERR_INVALID_ARG, "upload_tile: bad index %d or null tile", idx);
-    NL_HIP(hipMemcpyAsync(h->d_frames + (int64_t)idx * h->npix, host_tile,
+    NL_HIP(hipMemcpyAsync(h->d_frames + (int64_t)idx * h->fstride, host_tile,
                           (size_t)h->npix * sizeof(float), hipMemcpyHostToDevice, h->stream));
     NL_HIP(hipStreamSynchronize(h->stream));   // pointer must not be retained (cgo rules)
     return NL_OK;
@@ -582,7 +613,7 @@ int nl_stack_upload_frame_async(nl_stack_t *h, int idx, const float *host_frame)
     int slot = 0;
     int rc = stage_host_bytes(h, host_frame + (int64_t)h->row0 * h->width, bytes, &dst, &slot);
     if (rc != NL_OK) return rc;
-    NL_HIP(hipMemcpyAsync(h->d_frames + (int64_t)idx * h->npix, dst, bytes, hipMemcpyHostToDevice, h->copy_stream));
+    NL_HIP(hipMemcpyAsync(h->d_frames + (int64_t)idx * h->fstride, dst, bytes, hipMemcpyHostToDevice, h->copy_stream));
     return stage_done(h, slot);
 }
 
@@ -601,7 +632,7 @@ int nl_stack_download_tile(nl_stack_t *h, int idx, float *host_tile)
     NL_SETTLE_UPLOADS(h);
     if (idx < 0 || idx >= h->n_frames || !host_tile)
         return fail(NL_ERR_INVALID_ARG, "download_tile: bad index %d or null tile", idx);
-    NL_HIP(hipMemcpyAsync(host_tile, h->d_frames + (int64_t)idx * h->npix,
+    NL_HIP(hipMemcpyAsync(host_tile, h->d_frames + (int64_t)idx * h->fstride,
                           (size_t)h->npix * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     NL_HIP(hipStreamSynchronize(h->stream));
     return NL_OK;
@@ -615,7 +646,7 @@ int nl_stack_download_rows(nl_stack_t *h, int idx, int first_row, int n_rows, fl
         (int64_t)first_row + n_rows > h->rows)
         return fail(NL_ERR_INVALID_ARG, "download_rows: bad index %d, rows [%d,%d) of %d, or null buffer",
                     idx, first_row, first_row + n_rows, h->rows);
-    const float *src = (idx < 0 ? h->d_out : h->d_frames + (int64_t)idx * h->npix) + (int64_t)first_row * h->width;
+    const float *src = (idx < 0 ? h->d_out : h->d_frames + (int64_t)idx * h->fstride) + (int64_t)first_row * h->width;
     NL_HIP(hipMemcpyAsync(host_rows, src, (size_t)n_rows * h->width * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     NL_HIP(hipStreamSynchronize(h->stream));
     return NL_OK;
@@ -630,7 +661,7 @@ int64_t nl_stack_device_bytes(nl_stack_t *h)
     if (!h) return 0;
     const int64_t np = h->npix;
     int64_t b = 0;
-    if (h->d_frames_owned) b += np * 4 * h->n_capacity;
+    if (h->d_frames_owned) b += h->fstride_owned * 4 * h->n_capacity;
     if (h->d_out) b += np * 4;
     if (h->d_acc) b += np * 4;
     if (h->d_weights) b += 4 * (int64_t)h->n_capacity;
@@ -660,17 +691,43 @@ void *nl_stack_result_device_ptr(nl_stack_t *h) { return h ? h->d_out : nullptr;
 int nl_stack_last_mode(nl_stack_t *h) { return h ? h->last_mode : -1; }
 const char *nl_stack_last_kernel_name(nl_stack_t *h) { return h ? h->last_kernel : ""; }
 
+int nl_stack_attach_device_frames_strided(nl_stack_t *h, void *device_frames, int64_t frame_stride)
+{
+    NL_CHECK_HANDLE(h);
+    if (!device_frames) {
+        h->d_frames = h->d_frames_owned;
+        h->fstride = h->fstride_owned;
+        return NL_OK;
+    }
+    // the kernels address 4 frames + a pixel with one signed 32-bit byte offset (fast_common.hpp gather_sorted,
+    // fast_ml_common.hpp ml_gather_raw) and load 16 bytes per lane where the stride allows; the owned buffer's stride
+    // is chosen inside these limits, a lent one is checked
+    if (frame_stride < h->npix)
+        return fail(NL_ERR_INVALID_ARG, "attach_device_frames: stride %lld < %lld pixels of the tile",
+                    (long long)frame_stride, (long long)h->npix);
+    if (h->npix < nl::kFastMaxPixels && !frame_stride_addressable(h->npix, frame_stride))
+        return fail(NL_ERR_INVALID_ARG, "attach_device_frames: stride %lld too large for the tile's 32-bit frame offsets",
+                    (long long)frame_stride);
+    h->d_frames = static_cast<float *>(device_frames);
+    h->fstride = frame_stride;
+    return NL_OK;
+}
+
 int nl_stack_attach_device_frames(nl_stack_t *h, void *device_frames)
 {
     NL_CHECK_HANDLE(h);
-    h->d_frames = device_frames ? static_cast<float *>(device_frames) : h->d_frames_owned;
-    return NL_OK;
+    return nl_stack_attach_device_frames_strided(h, device_frames, h->npix);
+}
+
+int64_t nl_stack_frame_stride(nl_stack_t *h)
+{
+    return h ? h->fstride : 0;
 }
 
 int nl_stack_fill_synthetic(nl_stack_t *h, uint64_t seed)
 {
     NL_CHECK_HANDLE(h);
-    NL_HIP(nl::launch_fill_synthetic(h->d_frames, h->npix, h->n_frames, h->width, h->height,
+    NL_HIP(nl::launch_fill_synthetic(h->d_frames, h->fstride, h->n_frames, h->width, h->height,
                                      h->row0, h->rows, seed, h->stream));
     NL_HIP(hipStreamSynchronize(h->stream));
     return NL_OK;
@@ -993,7 +1050,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
 
     nl::StackArgs a;
     a.frames = h->d_frames;
-    a.stride = h->npix;
+    a.stride = h->fstride;
     a.npix = h->npix;
     a.n_frames = h->n_frames;
     a.n_pad = next_pow2(h->n_frames);
@@ -1839,7 +1896,7 @@ int nl_stack_frame_stats(nl_stack_t *h, int idx, float *mn, float *mean, float *
     NL_CHECK_HANDLE(h);
     NL_SETTLE_UPLOADS(h);
     if (idx < 0 || idx >= h->n_frames) return fail(NL_ERR_INVALID_ARG, "frame_stats: bad index %d", idx);
-    return frame_stats_impl(h, h->d_frames + (int64_t)idx * h->npix, h->npix, mn, mean, mx, variance);
+    return frame_stats_impl(h, h->d_frames + (int64_t)idx * h->fstride, h->npix, mn, mean, mx, variance);
 }
 
 static int frame_noise_impl(nl_stack_t *h, const float *d, float *noise)
@@ -1869,7 +1926,7 @@ int nl_stack_frame_noise(nl_stack_t *h, int idx, float *noise)
     if (h->row0 != 0 || h->rows != h->height)
         return fail(NL_ERR_INVALID_ARG, "frame_noise needs a whole-image handle (3x3 stencil)");
     if (h->width < 3 || h->height < 3) return fail(NL_ERR_INVALID_ARG, "frame_noise: image too small");
-    return frame_noise_impl(h, h->d_frames + (int64_t)idx * h->npix, noise);
+    return frame_noise_impl(h, h->d_frames + (int64_t)idx * h->fstride, noise);
 }
 
 int nl_stack_weights_from_noise(nl_stack_t *h, float *noise_out)
@@ -1951,7 +2008,7 @@ int nl_stack_upload_frame_fits(nl_stack_t *h, int idx, const void *raw_host, int
     NL_HIP(hipMemcpyAsync(h->d_ingest, raw_host, bytes, hipMemcpyHostToDevice, h->stream));
     const bool affine = !(multiplier == 1.0f && offset == 0.0f);
     NL_HIP(nl::launch_fits_decode(h->d_ingest, bitpix, h->npix, bscale, bzero, affine, multiplier, offset,
-                                  h->d_frames + (int64_t)idx * h->npix, h->d_stat_partial, kStatBlocks,
+                                  h->d_frames + (int64_t)idx * h->fstride, h->d_stat_partial, kStatBlocks,
                                   h->stream));
     if (stats_out) return decode_stats(h, h->npix, stats_out);
     NL_HIP(hipStreamSynchronize(h->stream));          // the caller's buffer must not be read after return
@@ -1975,7 +2032,7 @@ int nl_stack_upload_frame_projected(nl_stack_t *h, int idx, const float *src_hos
     NL_HIP(hipMemcpyAsync(h->d_ingest, src_host, bytes, hipMemcpyHostToDevice, h->stream));
     const bool affine = !(multiplier == 1.0f && offset == 0.0f);
     NL_HIP(nl::launch_project(static_cast<const float *>(h->d_ingest), src_w, src_h,
-                              h->d_frames + (int64_t)idx * h->npix, h->width, h->row0, h->rows, inv,
+                              h->d_frames + (int64_t)idx * h->fstride, h->width, h->row0, h->rows, inv,
                               out_of_bounds, affine, multiplier, offset, h->stream));
     NL_HIP(hipStreamSynchronize(h->stream));
     return NL_OK;
@@ -2014,7 +2071,7 @@ int nl_stack_upload_frame_fits_async(nl_stack_t *h, int idx, const void *raw_hos
     NL_HIP(hipMemcpyAsync(h->d_ingest_async, staged, bytes, hipMemcpyHostToDevice, h->copy_stream));
     const bool affine = !(multiplier == 1.0f && offset == 0.0f);
     NL_HIP(nl::launch_fits_decode(h->d_ingest_async, bitpix, h->npix, bscale, bzero, affine, multiplier, offset,
-                                  h->d_frames + (int64_t)idx * h->npix, h->d_stat_partial_async, kStatBlocks,
+                                  h->d_frames + (int64_t)idx * h->fstride, h->d_stat_partial_async, kStatBlocks,
                                   h->copy_stream));
     return stage_done(h, slot);
 }
@@ -2040,7 +2097,7 @@ int nl_stack_upload_frame_projected_async(nl_stack_t *h, int idx, const float *s
     NL_HIP(hipMemcpyAsync(h->d_ingest_async, staged, bytes, hipMemcpyHostToDevice, h->copy_stream));
     const bool affine = !(multiplier == 1.0f && offset == 0.0f);
     NL_HIP(nl::launch_project(static_cast<const float *>(h->d_ingest_async), src_w, src_h,
-                              h->d_frames + (int64_t)idx * h->npix, h->width, h->row0, h->rows, inv,
+                              h->d_frames + (int64_t)idx * h->fstride, h->width, h->row0, h->rows, inv,
                               out_of_bounds, affine, multiplier, offset, h->copy_stream));
     return stage_done(h, slot);
 }
@@ -2050,7 +2107,7 @@ int nl_stack_frame_affine(nl_stack_t *h, int idx, float multiplier, float offset
     NL_CHECK_HANDLE(h);
     NL_SETTLE_UPLOADS(h);
     if (idx < 0 || idx >= h->n_frames) return fail(NL_ERR_INVALID_ARG, "frame_affine: bad index %d", idx);
-    NL_HIP(nl::launch_affine(h->d_frames + (int64_t)idx * h->npix, h->npix, multiplier, offset, h->stream));
+    NL_HIP(nl::launch_affine(h->d_frames + (int64_t)idx * h->fstride, h->npix, multiplier, offset, h->stream));
     NL_HIP(hipStreamSynchronize(h->stream));
     return NL_OK;
 }

@@ -106,8 +106,16 @@ class StackHandle:
     def frames_device_ptr(self):
         return self._lib.nl_stack_frames_device_ptr(self._h)
 
-    def attach_device_frames(self, ptr):
-        capi.check(self._lib.nl_stack_attach_device_frames(self._h, C.c_void_p(ptr)))
+    def frame_stride(self):
+        """Floats between consecutive frames of the buffer frames_device_ptr() points at."""
+        return int(self._lib.nl_stack_frame_stride(self._h))
+
+    def attach_device_frames(self, ptr, stride=None):
+        """Lends a device buffer (None restores the owned one); `stride` in floats, default dense (rows*width)."""
+        if stride is None or ptr is None:
+            capi.check(self._lib.nl_stack_attach_device_frames(self._h, C.c_void_p(ptr)))
+        else:
+            capi.check(self._lib.nl_stack_attach_device_frames_strided(self._h, C.c_void_p(ptr), int(stride)))
 
     def set_active_frames(self, n):
         """Use frame slots [0, n) for the next uploads / passes (n <= the count given at creation)."""

@@ -884,3 +884,69 @@ def test_extreme_magnitudes_weighted_dispatch(nl, oracle, mode, n, scale):
     got, gc, want, wc = run_both(nl, oracle, mode, frames, width, height, w, 2.75, 2.75, exact=False)
     assert gc == wc, (gc, wc)
     assert same_values(got, want), describe_mismatch(got, want)
+
+
+# ---- round 5: padded frame stride -------------------------------------------------------------------------------
+# Large tiles get a padded frame stride by default (nlstack_api.hip padded_frame_stride); the small images of this
+# file stay dense, so the padded layout is forced here through every kernel family: the results must be the BITS of
+# the dense layout -- the stride only moves the frames, never the arithmetic -- and the oracle's counters.
+@pytest.mark.parametrize("pad", [4, 16448])
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("n", [5, 16, 24, 32, 100, 128, 200, 256, 300, 512])
+@pytest.mark.parametrize("mode", sorted(MODES))
+def test_padded_frame_stride_gives_the_dense_layout_s_bits(nl, oracle, monkeypatch, mode, n, weighted, pad):
+    if weighted and mode in (0, 4, 5):
+        pytest.skip("mode ignores weights / MADSigma with weights is unimplemented in the reference")
+    width, height = 131, 9
+    frames = make_frames(n, width, height, seed=9100 + 13 * n + mode, nan_frac=0.02)
+    w = np.random.default_rng(n + mode).uniform(0.2, 1.0, n).astype(np.float32) if weighted else None
+
+    def run(stride_pad):
+        monkeypatch.setenv("NL_STRIDE_PAD", str(stride_pad))
+        with nl.StackHandle(n, width, height) as st:
+            assert st.frame_stride() == width * height + stride_pad
+            st.upload_frames(frames)
+            st.set_weights(w)
+            out, cl, ch = st.run(mode, 2.75, 2.75, 0.5)
+            back = st.download_tile(n - 1)
+            stats = st.frame_stats(n // 2)
+            return out, (cl, ch), back, stats
+
+    dense, dc, dback, dstats = run(0)
+    padded, pc, pback, pstats = run(pad)
+    assert pc == dc and bits_equal(padded, dense), "%s n=%d pad %d: %s" % (MODES[mode], n, pad,
+                                                                            describe_mismatch(padded, dense))
+    assert bits_equal(pback, frames[n - 1].reshape(pback.shape)) and bits_equal(dback, pback)
+    assert np.array_equal(np.asarray(pstats, dtype=np.float64), np.asarray(dstats, dtype=np.float64), equal_nan=True)
+    if mode >= 2:
+        rc, want, wl, wh, _ = oracle.stack_apply(mode, frames, w, 2.75, 2.75, 0.5, num_cpu=4)
+        assert rc == 0 and pc == (wl, wh)
+
+
+def test_default_frame_stride_and_lent_frames(nl):
+    # large tiles: stride = pixels rounded up to 32768 floats + 16448; a second handle borrows the padded buffer with
+    # the lender's stride, a dense device buffer with the plain attach; both give the owner's bits
+    import torch
+    n, width, height = 24, 1024, 300
+    frames = make_frames(n, width, height, seed=77, nan_frac=0.01)
+    with nl.StackHandle(n, width, height) as st, nl.StackHandle(n, width, height) as h2:
+        npix = width * height
+        assert st.frame_stride() == (npix + 32767) // 32768 * 32768 + 16448
+        assert st.device_bytes >= st.frame_stride() * 4 * n
+        st.upload_frames(frames)
+        want, wl, wh = st.run(2, 2.5, 2.5)
+        h2.attach_device_frames(st.frames_device_ptr(), st.frame_stride())
+        assert h2.frame_stride() == st.frame_stride()
+        got, cl, ch = h2.run(2, 2.5, 2.5)
+        assert (cl, ch) == (wl, wh) and bits_equal(got, want)
+        dense = torch.from_numpy(frames.reshape(n, npix)).to("cuda:0").contiguous()
+        h2.attach_device_frames(dense.data_ptr())
+        assert h2.frame_stride() == npix
+        got, cl, ch = h2.run(2, 2.5, 2.5)
+        assert (cl, ch) == (wl, wh) and bits_equal(got, want)
+        with pytest.raises(Exception):
+            h2.attach_device_frames(dense.data_ptr(), npix - 4)
+        h2.attach_device_frames(None)
+        assert h2.frame_stride() == st.frame_stride()
+    with nl.StackHandle(8, 131, 9) as small:
+        assert small.frame_stride() == 131 * 9          # small tiles stay dense

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """(Lives under tests/ because it uses the CPU oracle.)
 Randomised differential test (run on the GPU box): random frame counts, modes, sigmas, NaN
-fractions, ties, infinities and tile geometry through the default dispatch of the C ABI against
+fractions, ties, infinities, tile geometry and frame stride through the default dispatch of the C ABI against
 the oracle.  Counters must be identical, values bit-exact or within 1e-5 depending on the kernel.
 usage: fuzz_parity.py [cases] [seed]
 NL_FUZZ_N=lo,hi restricts the frame counts, NL_FUZZ_MODES=2,3 the modes (a kernel class under test),
@@ -57,6 +57,8 @@ for i in range(cases):
     if mode in (1, 2, 3) and rng.random() < float(os.environ.get("NL_FUZZ_WEIGHTED", "0.25")):
         weights = rng.uniform(0.2, 1.0, n).astype(np.float32)
     ref_loc = float(rng.choice([0.0, 7.5]))
+    # frame stride of the owned buffer (read per handle, nlstack_api.hip padded_frame_stride): dense or one of a few paddings
+    os.environ["NL_STRIDE_PAD"] = str(int(rng.choice([0, 0, 4, 64, 1092, 16448])))
     with StackHandle(n, width, height, row0=row0, rows=rows) as st:
         st.upload_frames(frames)
         st.set_weights(weights)
@@ -73,8 +75,8 @@ for i in range(cases):
     good = rc == 0 and same_nan and (rel <= 1e-5) and (mode < 2 or (cl, ch) == (wl, wh))
     if not good:
         bad += 1
-        print("FAIL case %d: mode %d n=%d %dx%d rows[%d,%d) sl=%r sh=%r nan=%g weights=%s kernel=%s counters %r vs %r rel %.3g same_nan %s"
-              % (i, mode, n, width, height, row0, row0 + rows, sl, sh, nan_frac, weights is not None, kernel,
+        print("FAIL case %d: mode %d n=%d %dx%d rows[%d,%d) sl=%r sh=%r nan=%g weights=%s pad=%s kernel=%s counters %r vs %r rel %.3g same_nan %s"
+              % (i, mode, n, width, height, row0, row0 + rows, sl, sh, nan_frac, weights is not None, os.environ["NL_STRIDE_PAD"], kernel,
                  (cl, ch), (wl, wh), rel, same_nan), flush=True)
 print("fuzz: %d cases, %d failing, %.0f s" % (cases, bad, time.time() - t0))
 sys.exit(1 if bad else 0)

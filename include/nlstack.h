@@ -242,6 +242,8 @@ int nl_stack_set_exact(nl_stack_t *h, int on);
  * device memory, 352 bytes per pixel; also NL_MLZ_SPLIT=1) -- measured slower than the one-kernel pass, DESIGN.md section 5n.
  * bit 11 (2048) = the same class with persistent workgroups (three per CU looping over blocks of 64 pixels, no barrier: a block's
  * rounds run in one wave while the others sort the next block; also NL_MLZ_PERSIST=1) -- slower as well, same section.
+ * bit 13 (8192) = generic pass and first replay of a short-listed sigma pass on two streams (the protocol of rounds 2 - 4)
+ * instead of one launch (stack_tail_fused.hip; also NL_TAIL_FUSED=0), for A/B runs.
  * Default 0.  No counterpart in the reference. */
 int nl_stack_set_dev_flags(nl_stack_t *h, unsigned flags);
 /* Pixels of the last pass that were re-done by the exact kernel. */
@@ -249,6 +251,11 @@ int64_t nl_stack_last_fallback_pixels(nl_stack_t *h);
 /* Pixels of the last pass that the dominant kernel handed to the generic pass (all positions
  * masked by rank: pixels that miss many samples or clip more than the clip zones hold). */
 int64_t nl_stack_last_generic_pixels(nl_stack_t *h);
+/* How the last pass was enqueued (diagnostics; the results do not depend on it): bit 0 = fused protocol (no memset in front, no
+ * reduction kernel behind: sigma / winsorized passes once a handle knows its list lengths), bit 1 = generic pass and first
+ * replay as one launch (plain sigma, 65 ... 128 frames, short exact lists; stack_tail_fused.hip), bit 2 = chunked (experiments
+ * build).  No counterpart in the reference. */
+int nl_stack_last_pass_protocol(nl_stack_t *h);
 /* Linear-fit cascade of the last pass (stack_linfit.hip; StackLinearFit stack.go:834-918 has no
  * counterpart, diagnostics only): counts[s] = pixels stage s handed to stage s+1 (4 stages).
  * Writes min(n, 4) values; returns how many, 0 when the last pass ran no cascade. */

@@ -42,7 +42,7 @@ EXPORTS = [
     "nl_group_upload_frame", "nl_group_fill_synthetic", "nl_group_set_active_frames", "nl_group_set_weights", "nl_group_set_exact",
     "nl_group_run", "nl_group_last_mode", "nl_group_find_sigmas", "nl_group_accumulate",
     "nl_group_accumulate_finalize",
-    "nl_stack_set_exact", "nl_stack_set_dev_flags", "nl_stack_last_fallback_pixels", "nl_stack_last_generic_pixels",
+    "nl_stack_set_exact", "nl_stack_set_dev_flags", "nl_stack_last_fallback_pixels", "nl_stack_last_generic_pixels", "nl_stack_last_pass_protocol",
     "nl_stack_find_sigmas", "nl_stack_accumulate", "nl_stack_accumulate_finalize",
     "nl_stack_frame_stats", "nl_stack_frame_noise", "nl_stack_weights_from_noise",
     "nl_median_filter_3x3", "nl_median_filter_mask",
@@ -165,6 +165,7 @@ def load():
     L.nl_stack_last_fallback_pixels.argtypes = [vp]
     L.nl_stack_last_fallback_pixels.restype = C.c_int64
     L.nl_stack_last_generic_pixels.argtypes = [vp]
+    L.nl_stack_last_pass_protocol.argtypes = [vp]
     L.nl_stack_last_generic_pixels.restype = C.c_int64
     L.nl_stack_linfit_stage_counts.argtypes = [vp, C.POINTER(C.c_uint), C.c_int]
     L.nl_stack_linfit_stage_counts.restype = C.c_int

@@ -65,6 +65,7 @@ constexpr int kListGrid = 2048;     // workgroups of the exact kernel in fallbac
 constexpr int kCoopGrid = 16384;    // workgroups (one wave each) of the wave-per-pixel exact replay
 constexpr int kListLanes = 4;       // pixels per wave there: few pixels, keep divergence low
 constexpr unsigned kFusedMaxList = 512;    // exact-list length up to which a pass runs the fused protocol
+constexpr unsigned kTailFusedMaxList = 512;    // ... up to which generic pass and first replay share one launch (stack_tail_fused.hip)
 constexpr int kMaxChunks = 16;             // pixel ranges of a chunked pass
 // winsorization cascade, "clipping passes : winsorization rounds per pass : regions of the previous stage's list per
 // workgroup" for every stage (the last one runs to the end): measured on 4096^2 -- up to 40 frames
@@ -251,6 +252,7 @@ struct nl_stack {
     unsigned gen_hint = 0;                     // same for the generic list
     bool last_weighted = false;                // the last pass ran with weights (key of the hints it leaves)
     bool last_fused = false;
+    bool last_tail_fused = false;              // generic pass + first replay ran as one launch (stack_tail_fused.hip)
     bool last_lists = false;                   // the last pass left its list lengths behind the totals (d_counters[2])
     unsigned dev_flags = 0;                    // nl_stack_set_dev_flags (A/B measurements)
     unsigned *d_fb_list = nullptr;             // [npix] pixels the fast kernel handed to the exact kernel
@@ -1489,9 +1491,25 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
             if (err == hipSuccess) err = hipEventRecord(hh->ev_join, hh->side_stream);
             k->err = err;
         };
+        // Short exact lists (plain sigma, 65 ... 128 frames, fused protocol): generic pass and first replay as the lower and the
+        // upper workgroups of ONE launch (stack_tail_fused.hip) instead of two streams -- no fork, no join: the join alone costs
+        // a 512-row tile 14 us of its 257.  Every workgroup of that launch claims the generic pass's 48 KiB of LDS (three per
+        // CU), hence only while one wave per listed pixel fits the device at that rate.
+        // NL_TAIL_FUSED=0 / developer switch 8192: the two-stream protocol (A/B).
+        static const bool tail_fused_on = [] { const char *e = getenv("NL_TAIL_FUSED"); return !(e && e[0] == '0'); }();
+        const bool tail_fused = tail_fused_on && !(h->dev_flags & (8192u | 2u)) && fused && coop && !coop4 && !cascade &&
+                                nl::tail_fused_supported(mode, weighted, a.n_frames) != 0 && h->fb_hint != 0 &&
+                                h->fb_hint - 1u <= kTailFusedMaxList;
+        nl::StackArgs first_replay = e;
+        first_replay.list_snap = snap;                    // the list as the dominant kernel left it (snapshot on the device)
+        first_replay.list_part = 0;
+        unsigned replay_blocks = h->fb_hint + 31u;        // one wave per listed pixel and some: the list's length is last pass's
+        replay_blocks = replay_blocks < 64u ? 64u : replay_blocks > 768u ? 768u : replay_blocks;
+        if (tail_fused) after = nullptr;
         if (a.n_frames <= 128)
             NL_HIP(nl::launch_stack_sigma_fast(a, f, h->stream, &h->last_kernel, timed ? h->ev_dom1 : nullptr,
-                                               mode == NL_ST_WINSOR_SIGMA, after, &fork));
+                                               mode == NL_ST_WINSOR_SIGMA, after, &fork, nullptr,
+                                               tail_fused ? &first_replay : nullptr, replay_blocks));
         else   // 129..512 frames: 2 or 4 lanes per pixel
             NL_HIP(nl::launch_stack_sigma_ml(a, f, h->stream, &h->last_kernel, timed ? h->ev_dom1 : nullptr,
                                              mode == NL_ST_WINSOR_SIGMA, after, &fork));
@@ -1502,7 +1520,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
             e.list_part = 1;
             if (coop4) NL_HIP(NL_LAUNCH_COOP4(mode, e, grid1, h->stream, &exact_name));
             else       NL_HIP(nl::launch_stack_sigma_coop(mode, e, grid1, h->stream, &exact_name));
-            NL_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+            if (!tail_fused) NL_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         } else {
             int lanes = 0;
             size_t lds = 0;
@@ -1519,6 +1537,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
         }
         h->last_lists = true;
         h->last_fused = fused;
+        h->last_tail_fused = tail_fused;
         h->last_has_counters = true;
         h->last_used_fast = true;
     } else if ((h->exact_flavour == 3 ||
@@ -1615,6 +1634,7 @@ static int run_async_impl(nl_stack_t *h, int mode, float sigma_low, float sigma_
     NL_HIP(hipEventRecord(h->ev_stop, h->stream));
     h->partial_clean = zeroed_behind || keep_clean;
     if (!fused) h->last_fused = false;
+    if (!fused || !sigma_fast) h->last_tail_fused = false;
     if (!sigma_fast) h->last_lists = false;
     h->last_chunks = chunked ? plan.n : 0;
     h->pass_seq++;
@@ -1699,6 +1719,12 @@ int64_t nl_stack_last_fallback_pixels(nl_stack_t *h)
 {
     if (!h || !h->last_used_fast || !h->d_fb_count) return 0;
     return last_list_length(h, 0);
+}
+
+int nl_stack_last_pass_protocol(nl_stack_t *h)
+{
+    if (!h) return 0;
+    return (h->last_fused ? 1 : 0) | (h->last_tail_fused ? 2 : 0) | (h->last_chunks > 0 ? 4 : 0);
 }
 
 int64_t nl_stack_last_generic_pixels(nl_stack_t *h)

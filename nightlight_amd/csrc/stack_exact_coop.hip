@@ -381,10 +381,11 @@ __device__ float coop_select_median(float *a, unsigned short *lpos, unsigned sho
 // (profiles/r04_wsigma512_*).  With PF = 8 (257 ... 512 frames) every frame of the four pixels arrives in one 16-byte load
 // per lane; the registers cost wave slots the LDS columns of those depths had taken already.  Dispatched for the
 // winsorized replays only, see launch_coop.
+// The kernel's body, workgroup `block` of `nblocks` with its LDS columns at `a`: stack_sigma_coop_kernel below is the whole grid;
+// stack_tail_fused.hip runs it in the upper part of a grid whose lower workgroups are the generic pass.
 template <bool WINSOR, bool W, int GROUP, int PF = 2>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PF <= 2 ? 8 : 5, 8))) void stack_sigma_coop_kernel(StackArgs p)
+__device__ __forceinline__ void coop_body(const StackArgs &p, float *a, const unsigned block, const unsigned nblocks)
 {
-    extern __shared__ float a[];
     float *wz = a + p.n_frames;                   // winsorized copy (WINSOR only)
     float *wt = a + (WINSOR ? 2 : 1) * p.n_frames;          // weights (W only)
     unsigned short *lpos = reinterpret_cast<unsigned short *>(a + ((WINSOR ? 2 : 1) + (W ? 1 : 0)) * p.n_frames);   // partition scratch, 2 x n_frames x 16 bit
@@ -418,8 +419,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PF <= 2 ? 8 
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so with pixel = workgroup index the
     // neighbours sit on other XCDs and every line is fetched again and again (29.6 x the algorithmic bytes,
     // measured).  XCD x takes the x-th eighth of every sweep instead: neighbours run side by side under one L2.
-    int64_t wg = blockIdx.x;
-    if (!p.list && (gridDim.x & 7u) == 0u) wg = (int64_t)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    int64_t wg = block;
+    if (!p.list && (nblocks & 7u) == 0u) wg = (int64_t)(block & 7u) * (nblocks >> 3) + (block >> 3);
     // The first 128 frames of a pixel are gathered up front (two loads in flight), its decided rounds and their
     // bounds come with them (lane r holds round r), the weights of those frames sit in registers.
     static_assert(PF == 2 || GROUP == 4, "deep register prefetch is for the whole-tile replays");
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PF <= 2 ? 8 
         for (int c = 0; c < PF; c++) wreg[c] = c * 64 + lane < N ? p.weights[c * 64 + lane] : 0.0f;
     }
     if constexpr (GROUP > 1) limit = p.npix / GROUP;          // (never with a list; npix is a multiple of GROUP)
-    for (int64_t item = first + wg; item < limit; item += gridDim.x) {
+    for (int64_t item = first + wg; item < limit; item += nblocks) {
       float4 grp[PF];
       if constexpr (GROUP > 1) {
         static_assert(GROUP == 4, "one 16-byte load per lane and chunk");
@@ -624,14 +625,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PF <= 2 ? 8 
         // fused pass protocol (StackArgs::final): straight to the totals; the replay of the generic pass's
         // additions is the last kernel of a pass and leaves the list lengths behind them ({exact | generic << 32}:
         // the scratch layout of nlstack_api.hip) -- read back by nl_stack_finish with the totals
-        unsigned long long *slot = p.final ? p.final : p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+        unsigned long long *slot = p.final ? p.final : p.partial + 2 * (size_t)(block % kClipSlots);
         if (c_lo) atomicAdd(slot + 0, (unsigned long long)c_lo);
         if (c_hi) atomicAdd(slot + 1, (unsigned long long)c_hi);
-        if (p.final && p.list && p.list_part == 1 && blockIdx.x == 0)
+        if (p.final && p.list && p.list_part == 1 && block == 0)
             p.final[2] = (unsigned long long)p.list_count[0] | ((unsigned long long)p.list_count[1] << 32);
     }
 }
 
+template <bool WINSOR, bool W, int GROUP, int PF = 2>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PF <= 2 ? 8 : 5, 8))) void stack_sigma_coop_kernel(StackArgs p)
+{
+    extern __shared__ float a[];
+    coop_body<WINSOR, W, GROUP, PF>(p, a, blockIdx.x, gridDim.x);
+}
+
+#ifndef NL_TAIL_FUSED_TU          // (stack_tail_fused.hip includes this file for coop_body only)
 // StackMedian (stack.go:274-303) beyond the register kernels' 512 frames: gather and the
 // same wave-wide quickselect, nothing else.
 __global__ __launch_bounds__(64) void stack_median_coop_kernel(StackArgs p)
@@ -724,9 +733,11 @@ hipError_t launch_stack_sigma_coop(int mode, const StackArgs &args, int grid, hi
     return weighted ? launch_coop<false, true>(args, grid, lds, stream, name) : launch_coop<false, false>(args, grid, lds, stream, name);
 }
 
+#endif  // NL_TAIL_FUSED_TU
+
 }  // namespace nl
 
-#ifdef NL_PROBE
+#if defined(NL_PROBE) && !defined(NL_TAIL_FUSED_TU)
 extern "C" int nl_debug_probe(unsigned long long *out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nl::nl_probe_cycles), sizeof(nl::nl_probe_cycles)) != hipSuccess) return -1;

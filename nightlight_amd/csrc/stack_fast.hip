@@ -500,7 +500,8 @@ static inline void keep_first(hipError_t &acc, hipError_t e) { if (acc == hipSuc
 template <int NS, bool WINSOR>
 static hipError_t launch_pair(const StackArgs &args, const FastArgs &fargs, unsigned tile_blocks,
                               hipStream_t stream, const char **name, hipEvent_t dominant_done,
-                              AfterDominant after, void *user, hipStream_t tail)
+                              AfterDominant after, void *user, hipStream_t tail,
+                              const StackArgs *fused_replay, unsigned fused_replay_blocks)
 {
     hipError_t err = hipSuccess;
     FastArgs f = fargs;
@@ -579,7 +580,10 @@ static hipError_t launch_pair(const StackArgs &args, const FastArgs &fargs, unsi
             // is a few LDS reads instead of a pass over 128 masked registers -- this pass is pure
             // latency (a few hundred waves at most), and it sits on every pass's critical path
             const unsigned lblocks = generic_grid(fargs.gen_hint, 64, 4 * tile_blocks < 4 * kGenericGrid ? 4 * tile_blocks : 4 * kGenericGrid);
-            keep_first(err, launch_stack_sigma_mlg(args, f, lblocks, stream, WINSOR));
+            if (!WINSOR && fused_replay)      // generic pass + first replay in one grid (stack_tail_fused.hip)
+                keep_first(err, launch_stack_sigma_tail(args, f, lblocks, *fused_replay, fused_replay_blocks, stream));
+            else
+                keep_first(err, launch_stack_sigma_mlg(args, f, lblocks, stream, WINSOR));
         } else {
             hipLaunchKernelGGL((stack_sigma_fast_kernel<NS, false, WINSOR, false>), dim3(gblocks), dim3(256), 0,
                                stream, args, f);
@@ -599,30 +603,32 @@ static hipError_t launch_pair(const StackArgs &args, const FastArgs &fargs, unsi
 
 template <bool WINSOR>
 static hipError_t launch_sized(const StackArgs &args, const FastArgs &fargs, hipStream_t stream, const char **name,
-                         hipEvent_t dominant_done, AfterDominant after, void *user, hipStream_t tail)
+                         hipEvent_t dominant_done, AfterDominant after, void *user, hipStream_t tail,
+                         const StackArgs *fused_replay, unsigned fused_replay_blocks)
 {
     const unsigned blocks = (unsigned)((args.npix + 255) / 256);
     const int n = args.n_frames;
     // network sizes: the frame count rounded up to the next instantiated size;
     // unused positions count as missing samples
-    if (n <= 8)        return launch_pair<8, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
-    else if (n <= 16)  return launch_pair<16, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
-    else if (n <= 24)  return launch_pair<24, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
-    else if (n <= 32)  return launch_pair<32, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
-    else if (n <= 48)  return launch_pair<48, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
-    else if (n <= 64)  return launch_pair<64, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
-    else if (n <= 80)  return launch_pair<80, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
-    else if (n <= 96)  return launch_pair<96, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
-    else if (n <= 112) return launch_pair<112, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
-    else               return launch_pair<128, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail);
+    if (n <= 8)        return launch_pair<8, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail, fused_replay, fused_replay_blocks);
+    else if (n <= 16)  return launch_pair<16, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail, fused_replay, fused_replay_blocks);
+    else if (n <= 24)  return launch_pair<24, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail, fused_replay, fused_replay_blocks);
+    else if (n <= 32)  return launch_pair<32, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail, fused_replay, fused_replay_blocks);
+    else if (n <= 48)  return launch_pair<48, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail, fused_replay, fused_replay_blocks);
+    else if (n <= 64)  return launch_pair<64, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail, fused_replay, fused_replay_blocks);
+    else if (n <= 80)  return launch_pair<80, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail, fused_replay, fused_replay_blocks);
+    else if (n <= 96)  return launch_pair<96, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail, fused_replay, fused_replay_blocks);
+    else if (n <= 112) return launch_pair<112, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail, fused_replay, fused_replay_blocks);
+    else               return launch_pair<128, WINSOR>(args, fargs, blocks, stream, name, dominant_done, after, user, tail, fused_replay, fused_replay_blocks);
 }
 
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
                                    const char **name, hipEvent_t dominant_done,
-                                   bool winsor, AfterDominant after, void *user, hipStream_t tail)
+                                   bool winsor, AfterDominant after, void *user, hipStream_t tail,
+                                   const StackArgs *fused_replay, unsigned fused_replay_blocks)
 {
-    hipError_t err = winsor ? launch_sized<true>(args, fargs, stream, name, dominant_done, after, user, tail)
-                            : launch_sized<false>(args, fargs, stream, name, dominant_done, after, user, tail);
+    hipError_t err = winsor ? launch_sized<true>(args, fargs, stream, name, dominant_done, after, user, tail, fused_replay, fused_replay_blocks)
+                            : launch_sized<false>(args, fargs, stream, name, dominant_done, after, user, tail, fused_replay, fused_replay_blocks);
     keep_first(err, hipGetLastError());
     return err;
 }

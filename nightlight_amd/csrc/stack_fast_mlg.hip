@@ -141,9 +141,11 @@ __device__ __forceinline__ void range_moments(const float *col, float c, int i, 
 
 }  // namespace
 
+// The kernel's body, workgroup `block` of `nblocks` (stack_sigma_mlg_kernel below: the whole grid; stack_tail_fused.hip: the
+// lower workgroups of a grid whose upper part replays the dominant kernel's exact list -- `block` is blockIdx.x there too, the
+// fused protocol's helpers in fast_common.hpp address the first workgroup by it).
 template <int LPP, bool WINSOR>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
-void stack_sigma_mlg_kernel(StackArgs p, FastArgs q)
+__device__ __forceinline__ void mlg_body(const StackArgs &p, const FastArgs &q, const unsigned block, const unsigned nblocks)
 {
     using LY = MlgLayout<LPP>;
     constexpr int NS = LY::NS, NT = LY::NT, PW = LY::PW;
@@ -158,9 +160,9 @@ void stack_sigma_mlg_kernel(StackArgs p, FastArgs q)
 
     int c_lo_total = 0, c_hi_total = 0;
     const int64_t limit = q.in_list ? (int64_t)min(*q.in_count, q.in_capacity) : p.npix;
-    const int64_t sweep = (int64_t)gridDim.x * PW;
+    const int64_t sweep = (int64_t)nblocks * PW;
 
-    for (int64_t wg_item = (int64_t)blockIdx.x * PW; wg_item < limit; wg_item += sweep) {
+    for (int64_t wg_item = (int64_t)block * PW; wg_item < limit; wg_item += sweep) {
         int N = p.n_frames;
         asm volatile("" : "+s"(N));
         const int64_t item = wg_item + threadIdx.x / LPP;
@@ -396,6 +398,14 @@ void stack_sigma_mlg_kernel(StackArgs p, FastArgs q)
     }
 }
 
+template <int LPP, bool WINSOR>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void stack_sigma_mlg_kernel(StackArgs p, FastArgs q)
+{
+    mlg_body<LPP, WINSOR>(p, q, blockIdx.x, gridDim.x);
+}
+
+#ifndef NL_TAIL_FUSED_TU          // (stack_tail_fused.hip includes this file for mlg_body only)
 // generic pass over fargs.in_list (the hand-over list of a zonal kernel): 2 or 4 lanes per pixel for
 // 129..512 frames; one lane per pixel (64 pixels per wave, the same 48 KiB) for the winsorized
 // one-lane kernels of stack_fast.hip, whose register version of this pass runs 28 lock-step
@@ -416,5 +426,6 @@ hipError_t launch_stack_sigma_mlg(const StackArgs &args, const FastArgs &fargs, 
     }
     return hipGetLastError();
 }
+#endif  // NL_TAIL_FUSED_TU
 
 }  // namespace nl

@@ -232,9 +232,17 @@ hipError_t launch_stack_sigma_mlz(const StackArgs &args, const FastArgs &fargs, 
                                   bool winsor);
 // tail (optional): the stream the generic pass is launched on instead of `stream` -- chunked passes
 // (nlstack_api.hip), whose after_dominant callback orders it behind the dominant kernel
+// fused_replay (optional; tail_fused_supported): the generic pass and the replay of the exact list as the dominant kernel left
+// it run as ONE launch (stack_tail_fused.hip) -- *fused_replay are the replay's arguments (list part 0), in fused_replay_blocks
+// workgroups; after_dominant is then not needed for the replay
 hipError_t launch_stack_sigma_fast(const StackArgs &args, const FastArgs &fargs, hipStream_t stream,
                                    const char **name, hipEvent_t dominant_done,
-                                   bool winsor, AfterDominant after_dominant, void *user, hipStream_t tail = nullptr);
+                                   bool winsor, AfterDominant after_dominant, void *user, hipStream_t tail = nullptr,
+                                   const StackArgs *fused_replay = nullptr, unsigned fused_replay_blocks = 0);
+// ---- stack_tail_fused.hip: generic pass (one lane per pixel, LDS columns) + first replay in one grid; plain sigma, 65 ... 128 frames
+int tail_fused_supported(int mode, bool weighted, int n_frames);
+hipError_t launch_stack_sigma_tail(const StackArgs &generic, const FastArgs &fargs, unsigned gen_blocks,
+                                   const StackArgs &replay, unsigned replay_blocks, hipStream_t stream);
 
 constexpr int kCascadeStages = 6;   // most stages of a winsorization cascade, the dominant kernel included
 // rounds of clip bounds a decision pass records per pixel (pixels that need more are replayed in full)

@@ -173,6 +173,11 @@ class StackHandle:
         return int(self._lib.nl_stack_last_fallback_pixels(self._h))
 
     @property
+    def last_pass_protocol(self):
+        """Bit 0: fused protocol, bit 1: generic pass + first replay in one launch, bit 2: chunked (diagnostics)."""
+        return int(self._lib.nl_stack_last_pass_protocol(self._h))
+
+    @property
     def last_generic_pixels(self):
         return int(self._lib.nl_stack_last_generic_pixels(self._h))
 

@@ -950,3 +950,45 @@ def test_default_frame_stride_and_lent_frames(nl):
         assert h2.frame_stride() == st.frame_stride()
     with nl.StackHandle(8, 131, 9) as small:
         assert small.frame_stride() == 131 * 9          # small tiles stay dense
+
+
+# ---- round 5: generic pass and first replay as one launch (stack_tail_fused.hip) ---------------------------------------
+# Plain sigma clipping of 65 ... 128 frames with a short exact list runs the tail of a pass as ONE grid (generic pass in the
+# lower workgroups, bit-exact replay of the dominant kernel's hand-overs in the upper ones) instead of two streams with a
+# join.  The results must be the bits and counters of the two-stream protocol (developer switch 8192) and the oracle's
+# counters; queued passes with different kappas -- nothing but stream order between them now -- must end like single ones.
+@pytest.mark.parametrize("nan_frac", [0.0, 0.03])
+@pytest.mark.parametrize("n", [65, 80, 100, 127, 128])
+def test_generic_pass_and_first_replay_in_one_launch(nl, oracle, n, nan_frac):
+    width, height = 640, 24
+    frames = make_frames(n, width, height, seed=4200 + n, nan_frac=nan_frac, ties=bool(n & 1))
+    kappas = [(2.5, 2.5), (2.0, 3.2), (3.0, 2.2)]              # (exact lists of a few dozen pixels: the one-launch tail wants <= 512)
+    with nl.StackHandle(n, width, height) as st:
+        st.upload_frames(frames)
+        st.set_dev_flags(8192)
+        st.run(2, *kappas[0])                              # the first pass of a handle leaves the list lengths
+        two = [st.run(2, sl, sh) for sl, sh in kappas]
+        assert not (st.last_pass_protocol & 2)
+        st.set_dev_flags(0)
+        one, listed = [], []
+        for sl, sh in kappas:
+            one.append(st.run(2, sl, sh))
+            listed.append(st.last_fallback_pixels)
+            assert st.last_pass_protocol & 3 == 3, "pass protocol %d, exact lists %r" % (st.last_pass_protocol, listed)
+        assert 0 < max(listed) <= 512
+        for (a, al, ah), (b, bl, bh), (sl, sh) in zip(one, two, kappas):
+            assert (al, ah) == (bl, bh) and bits_equal(a, b), "kappa %r: %s" % ((sl, sh), describe_mismatch(a, b))
+            rc, want, wl, wh, _ = oracle.stack_apply(2, frames, None, sl, sh, 0.0, num_cpu=4)
+            assert rc == 0 and (al, ah) == (wl, wh) and close_values(a, want)
+        # queued: three passes of different kappas back to back, then the same order again; the last one's result stands
+        for sl, sh in kappas + kappas:
+            st.run_async(2, sl, sh, 0.0)
+        queued = np.zeros(width * height, np.float32)
+        cl, ch = st.finish(queued)
+        assert st.last_pass_protocol & 2
+        assert (cl, ch) == one[-1][1:] and bits_equal(queued, one[-1][0])
+        seen = set()
+        for _ in range(25):
+            out, cl, ch = st.run(2, *kappas[1])
+            seen.add((cl, ch, out.tobytes()))
+        assert len(seen) == 1

@@ -242,8 +242,11 @@ def main():
             if dist is not None and on_device:
                 k = seq[0] % 3
                 if works[k] is not None:
-                    with torch.cuda.stream(stream):
-                        works[k].wait()                     # (three passes old: long done; orders the reuse of the buffer)
+                    # (three passes old: long done -- a host-side query then, no wait on the pass's stream; the wait only if it
+                    # really is still running: it orders the reuse of the buffer)
+                    if not works[k].is_completed():
+                        with torch.cuda.stream(stream):
+                            works[k].wait()
                     works[k] = None
                 st.set_counters_buffer(ring[k].data_ptr())
             st.run_async(mode, args.kappa, args.kappa, 0.0)

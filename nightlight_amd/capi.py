@@ -37,7 +37,7 @@ EXPORTS = [
     "nl_stack_set_active_frames", "nl_stack_set_weights", "nl_weights_from_scalars",
     "nl_stack_linfit_stage_counts", "nl_stack_run", "nl_stack_run_async", "nl_stack_finish", "nl_stack_result_device_ptr",
     "nl_stack_last_mode", "nl_stack_last_kernel_ms", "nl_stack_last_dominant_kernel_ms",
-    "nl_stack_last_kernel_name", "nl_stack_pass_times", "nl_stack_stream", "nl_stack_counters_device_ptr", "nl_stack_copy_counters_async", "nl_stack_set_counters_buffer",
+    "nl_stack_last_kernel_name", "nl_stack_pass_times", "nl_stack_stream", "nl_stack_counters_device_ptr", "nl_stack_copy_counters_async", "nl_stack_set_counters_buffer", "nl_stack_order_stream_after",
     "nl_group_tile_rows", "nl_group_create", "nl_group_destroy", "nl_group_size", "nl_group_tile",
     "nl_group_upload_frame", "nl_group_fill_synthetic", "nl_group_set_active_frames", "nl_group_set_weights", "nl_group_set_exact",
     "nl_group_run", "nl_group_last_mode", "nl_group_find_sigmas", "nl_group_accumulate",
@@ -142,6 +142,7 @@ def load():
     L.nl_stack_counters_device_ptr.restype = vp
     L.nl_stack_copy_counters_async.argtypes = [vp, vp]
     L.nl_stack_set_counters_buffer.argtypes = [vp, vp]
+    L.nl_stack_order_stream_after.argtypes = [vp, vp]
     L.nl_stack_set_counters_buffer.restype = C.c_int
     L.nl_group_tile_rows.argtypes = [C.c_int, C.c_int, C.c_int, _intp, _intp]
     L.nl_group_tile_rows.restype = None

@@ -64,6 +64,7 @@ constexpr int kStatBlocks = 2048;
 constexpr int kListGrid = 2048;     // workgroups of the exact kernel in fallback-list mode
 constexpr int kCoopGrid = 16384;    // workgroups (one wave each) of the wave-per-pixel exact replay
 constexpr int kListLanes = 4;       // pixels per wave there: few pixels, keep divergence low
+constexpr int kOrderRing = 8;              // events nl_stack_order_stream_after cycles through
 constexpr unsigned kFusedMaxList = 512;    // exact-list length up to which a pass runs the fused protocol
 constexpr unsigned kTailFusedMaxList = 512;    // ... up to which generic pass and first replay share one launch (stack_tail_fused.hip)
 constexpr int kMaxChunks = 16;             // pixel ranges of a chunked pass
@@ -232,6 +233,8 @@ struct nl_stack {
     hipEvent_t ev_dom0 = nullptr, ev_dom1 = nullptr;
     hipStream_t side_stream = nullptr;                     // replay of the dominant kernel's hand-overs,
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;        // concurrent with the generic pass
+    hipEvent_t ev_order[kOrderRing] = {};                   // nl_stack_order_stream_after
+    int order_seq = 0;
     unsigned ev_rel = 0;                                   // creation flag of the pass's events (hipEventDisableSystemFence or 0)
     float *d_frames_owned = nullptr;  // [n_frames][npix]
     float *d_frames = nullptr;        // owned or lent
@@ -429,6 +432,7 @@ static int destroy_impl(nl_stack_t *h)
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    for (hipEvent_t &ev : h->ev_order) if (ev) (void)hipEventDestroy(ev);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1788,6 +1792,18 @@ int nl_stack_set_counters_buffer(nl_stack_t *h, void *device_buf)
 {
     NL_CHECK_HANDLE(h);
     h->d_counters = device_buf ? static_cast<unsigned long long *>(device_buf) : h->d_counters_own;
+    return NL_OK;
+}
+
+int nl_stack_order_stream_after(nl_stack_t *h, void *hip_stream)
+{
+    NL_CHECK_HANDLE(h);
+    if (!hip_stream) return fail(NL_ERR_INVALID_ARG, "order_stream_after: null stream");
+    // a ring of events: the waiting stream may still be working off an older one when the next pass is enqueued
+    const int slot = h->order_seq++ % kOrderRing;
+    if (!h->ev_order[slot]) NL_HIP(hipEventCreateWithFlags(&h->ev_order[slot], hipEventDisableTiming | h->ev_rel));
+    NL_HIP(hipEventRecord(h->ev_order[slot], h->stream));
+    NL_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), h->ev_order[slot], 0));
     return NL_OK;
 }
 

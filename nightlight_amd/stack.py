@@ -224,6 +224,10 @@ class StackHandle:
         """Passes enqueued from now on leave their counters in the caller's device buffer (32 bytes; None: the handle's own)."""
         capi.check(self._lib.nl_stack_set_counters_buffer(self._h, C.c_void_p(int(device_ptr)) if device_ptr else None))
 
+    def order_stream_after(self, hip_stream):
+        """`hip_stream` (integer hipStream_t) waits for everything enqueued on the handle so far."""
+        capi.check(self._lib.nl_stack_order_stream_after(self._h, C.c_void_p(int(hip_stream))))
+
     @property
     def counters_device_ptr(self):
         """Device address of the last pass's {clip_low, clip_high} (2 x int64)."""

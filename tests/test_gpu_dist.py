@@ -230,20 +230,25 @@ def _rccl_worker(_index, port, out_path):
     # round 5, what bench.py does now: no copy kernel -- pass i leaves its counters in ring[i % 3] (the caller's buffer,
     # nl_stack_set_counters_buffer), the all-reduce runs in place on it while pass i + 1 has the device, a buffer is
     # handed out again behind the collective that used it last
+    # ... and the collectives are issued from a stream of their own that waits for pass i through nl_stack_order_stream_after
+    # (the pass's stream waits for nothing but a buffer's last collective, and that only if a host-side query finds it running)
     ring = torch.zeros((3, 4), dtype=torch.int64, device="cuda")
     works = [None, None, None]
+    comm = torch.cuda.Stream()
     for it in range(7):
         k = it % 3
-        if works[k] is not None:
+        if works[k] is not None and (it == 4 or not works[k].is_completed()):      # (it == 4: the waiting branch, once)
             with torch.cuda.stream(stream):
                 works[k].wait()
         st.set_counters_buffer(ring[k].data_ptr())
         st.run_async(2, 2.5 + 0.25 * (it % 4), 2.5)
-        with torch.cuda.stream(stream):
+        st.order_stream_after(comm.cuda_stream)
+        with torch.cuda.stream(comm):
             works[k] = dist.all_reduce(ring[k][:2], async_op=True)
-    with torch.cuda.stream(stream):
+    with torch.cuda.stream(comm):
         for w_ in works:
             w_.wait()
+    comm.synchronize()
     st.finish()
     torch.cuda.synchronize()
     ring_totals = ring[:, :2].cpu().numpy()                 # passes 6, 4, 5 (it = 6 -> k = 0, 4 -> 1, 5 -> 2)

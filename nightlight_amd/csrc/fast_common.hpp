@@ -56,9 +56,11 @@ __device__ __forceinline__ void fused_prologue_dominant(const StackArgs &p)
     }
 }
 // generic pass, first wave of the first workgroup: the dominant kernel's sharded counts -> totals
-__device__ __forceinline__ void fused_collect_slots(const StackArgs &p)
+// (`block`: this workgroup's index within the generic pass -- its position in the grid unless the pass shares a grid,
+// stack_tail_fused.hip)
+__device__ __forceinline__ void fused_collect_slots(const StackArgs &p, unsigned block)
 {
-    if (p.final && blockIdx.x == 0 && threadIdx.x < 64) {
+    if (p.final && block == 0 && threadIdx.x < 64) {
         unsigned long long lo = 0, hi = 0;
         for (int i = threadIdx.x; i < kClipSlots; i += 64) {
             lo += p.partial[2 * (size_t)i];
@@ -76,9 +78,9 @@ __device__ __forceinline__ void fused_collect_slots(const StackArgs &p)
     }
 }
 // where a kernel that runs AFTER the dominant one adds its clip counts: the totals, or (plain protocol) a shard
-__device__ __forceinline__ unsigned long long *clip_slot(const StackArgs &p)
+__device__ __forceinline__ unsigned long long *clip_slot(const StackArgs &p, unsigned block)
 {
-    return p.final ? p.final : p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
+    return p.final ? p.final : p.partial + 2 * (size_t)(block % kClipSlots);
 }
 
 // compile-time loops: every index is a constant, so register columns never

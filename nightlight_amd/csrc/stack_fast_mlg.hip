@@ -142,15 +142,14 @@ __device__ __forceinline__ void range_moments(const float *col, float c, int i, 
 }  // namespace
 
 // The kernel's body, workgroup `block` of `nblocks` (stack_sigma_mlg_kernel below: the whole grid; stack_tail_fused.hip: the
-// lower workgroups of a grid whose upper part replays the dominant kernel's exact list -- `block` is blockIdx.x there too, the
-// fused protocol's helpers in fast_common.hpp address the first workgroup by it).
+// upper workgroups of a grid whose lower part replays the dominant kernel's exact list).
 template <int LPP, bool WINSOR>
 __device__ __forceinline__ void mlg_body(const StackArgs &p, const FastArgs &q, const unsigned block, const unsigned nblocks)
 {
     using LY = MlgLayout<LPP>;
     constexpr int NS = LY::NS, NT = LY::NT, PW = LY::PW;
     __shared__ float lds[LY::ROWS * PW];
-    if (q.in_list) { fused_collect_slots(p); snapshot_fb_list(q); }
+    if (q.in_list) { fused_collect_slots(p, block); snapshot_fb_list(q); }
 
     const int lane = threadIdx.x & 63;
     const int role = threadIdx.x % LPP;
@@ -392,7 +391,7 @@ __device__ __forceinline__ void mlg_body(const StackArgs &p, const FastArgs &q, 
         c_hi_total += __shfl_xor(c_hi_total, o, 64);
     }
     if (lane == 0) {
-        unsigned long long *slot = clip_slot(p);
+        unsigned long long *slot = clip_slot(p, block);
         if (c_lo_total) atomicAdd(slot + 0, (unsigned long long)c_lo_total);
         if (c_hi_total) atomicAdd(slot + 1, (unsigned long long)c_hi_total);
     }

@@ -59,7 +59,7 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
     static_assert(!CONT || (ZONAL && WINSOR && !RECORD), "CONT continues a winsorized zonal pass");
     constexpr bool CASCADE = ZONAL && WINSOR && !RECORD;      // this instantiation knows about budgets and continuation lists
     if constexpr (ZONAL && !RECORD && !CONT) fused_prologue_dominant(p);
-    if constexpr (!ZONAL) { if (q.in_list) { fused_collect_slots(p); snapshot_fb_list(q); } }
+    if constexpr (!ZONAL) { if (q.in_list) { fused_collect_slots(p, blockIdx.x); snapshot_fb_list(q); } }
     // zone widths: 8 clipped + 8 missing samples per lane for the larger
     // networks, 4 + 4 for the small ones
     // (zones of 8 for the winsorized 24- and 32-position kernels were measured: 553 k -> 86 k pixels in the generic pass
@@ -709,7 +709,7 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
         int t_lo = 0, t_hi = 0;
         for (unsigned w = 0; w < (blockDim.x >> 6); w++) { t_lo += s_lo[w]; t_hi += s_hi[w]; }
         unsigned long long *slot = p.partial + 2 * (size_t)(blockIdx.x % kClipSlots);
-        if constexpr (!ZONAL) slot = clip_slot(p);
+        if constexpr (!ZONAL) slot = clip_slot(p, blockIdx.x);
         if (t_lo) atomicAdd(slot + 0, (unsigned long long)t_lo);
         if (t_hi) atomicAdd(slot + 1, (unsigned long long)t_hi);
     }

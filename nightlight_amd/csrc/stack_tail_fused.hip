@@ -8,8 +8,8 @@
 // itself runs longer behind it (kernel timelines) -- a tenth of a 512-row tile's pass.  HIP offers no
 // other way for two kernels of one stream to overlap on gfx9 (hipExtAnyOrderLaunch is ignored there: measured).
 //
-// Here the two kernels are the lower and the upper workgroups of one grid: workgroups [0, gen_blocks) run mlg_body, the rest
-// coop_body on the exact list as the dominant kernel left it (list part 0; the snapshot protocol of fast_common.hpp does not
+// Here the two kernels are the upper and the lower workgroups of one grid: the last gen_blocks workgroups run mlg_body, the
+// others coop_body on the exact list as the dominant kernel left it (list part 0; the snapshot protocol of fast_common.hpp does not
 // care who looks first).  The replay of what the generic pass adds to the list follows as before.  Every workgroup claims the
 // generic pass's 48 KiB of LDS, so three replay workgroups fit a CU: dispatched only while the exact list is short
 // (nlstack_api.hip: kTailFusedMaxList), which is where the join weighs most.
@@ -25,8 +25,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void stack_sigma_tail_kernel(StackArgs pg, FastArgs qg, StackArgs pe, unsigned gen_blocks)
 {
     extern __shared__ float replay_columns[];
-    if (blockIdx.x < gen_blocks) mlg_body<1, false>(pg, qg, blockIdx.x, gen_blocks);
-    else coop_body<false, false, 1, 2>(pe, replay_columns, blockIdx.x - gen_blocks, gridDim.x - gen_blocks);
+    // (the replay's workgroups first: the generic pass's waves are the long pole -- behind the replay's they start a
+    // microsecond later; in front of them the replay's last workgroups started, and the grid ended, 5 us later)
+    const unsigned replay_blocks = gridDim.x - gen_blocks;
+    if (blockIdx.x < replay_blocks) coop_body<false, false, 1, 2>(pe, replay_columns, blockIdx.x, replay_blocks);
+    else mlg_body<1, false>(pg, qg, blockIdx.x - replay_blocks, gen_blocks);
 }
 
 int tail_fused_supported(int mode, bool weighted, int n_frames)

@@ -22,6 +22,7 @@ from oracle import oracle
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
+protocols = {}            # second passes by nl_stack_last_pass_protocol
 t0 = time.time()
 for i in range(cases):
     mode = int(rng.choice([0, 1, 2, 2, 3, 3, 4, 5, 5]))
@@ -64,6 +65,14 @@ for i in range(cases):
         st.set_weights(weights)
         got, cl, ch = st.run(mode, sl, sh, ref_loc)
         kernel = st.last_kernel_name
+        again_ok = True
+        if mode in (2, 3):
+            # a second pass on the handle knows its list lengths: fused protocol, generic pass + first replay in one launch
+            # where that applies -- it must end exactly like the first
+            got2, cl2, ch2 = st.run(mode, sl, sh, ref_loc)
+            again_ok = (cl2, ch2) == (cl, ch) and np.array_equal(got2.view(np.uint32), got.view(np.uint32))
+            kernel += " protocol %d" % st.last_pass_protocol
+            protocols[st.last_pass_protocol] = protocols.get(st.last_pass_protocol, 0) + 1
     got = got[row0 * width:(row0 + rows) * width]
     tile = np.ascontiguousarray(frames.reshape(n, height, width)[:, row0:row0 + rows, :].reshape(n, -1))
     ow = None if mode in (0, 5) else weights
@@ -72,11 +81,11 @@ for i in range(cases):
     ok = ~np.isnan(want) & (want != got)
     with np.errstate(all="ignore"):
         rel = float(np.nanmax(np.abs(got[ok].astype(np.float64) - want[ok]) / np.abs(want[ok].astype(np.float64)))) if ok.any() else 0.0
-    good = rc == 0 and same_nan and (rel <= 1e-5) and (mode < 2 or (cl, ch) == (wl, wh))
+    good = rc == 0 and same_nan and (rel <= 1e-5) and (mode < 2 or (cl, ch) == (wl, wh)) and again_ok
     if not good:
         bad += 1
-        print("FAIL case %d: mode %d n=%d %dx%d rows[%d,%d) sl=%r sh=%r nan=%g weights=%s pad=%s kernel=%s counters %r vs %r rel %.3g same_nan %s"
+        print("FAIL case %d: mode %d n=%d %dx%d rows[%d,%d) sl=%r sh=%r nan=%g weights=%s pad=%s kernel=%s counters %r vs %r rel %.3g same_nan %s second_pass_same %s"
               % (i, mode, n, width, height, row0, row0 + rows, sl, sh, nan_frac, weights is not None, os.environ["NL_STRIDE_PAD"], kernel,
-                 (cl, ch), (wl, wh), rel, same_nan), flush=True)
-print("fuzz: %d cases, %d failing, %.0f s" % (cases, bad, time.time() - t0))
+                 (cl, ch), (wl, wh), rel, same_nan, again_ok), flush=True)
+print("fuzz: %d cases, %d failing, %.0f s; second passes by protocol (bit 0 fused, bit 1 one-launch tail): %r" % (cases, bad, time.time() - t0, protocols))
 sys.exit(1 if bad else 0)

@@ -1,10 +1,11 @@
 // Developer microbenchmark: does the streaming rate of a 128-frame stack depend on WHICH allocation it lives in?
-// (median / mean 128 x 4096^2 run 8 % slower on about one handle in six.)  Eight allocations of
+// (median / mean 128 x 4096^2 run 8 % slower on about one handle in six.)  Eight (or argv[1], up to 28) allocations of
 // 8 GiB (+ slack), the same streaming kernel over each (one lane per pixel, 128 nontemporal loads in flight, a sum), three
 // rounds; prints the device address and the rate, and the rate again at a base shifted by 2 MiB and by 64 KiB.
 //   hipcc --offload-arch=gfx950 -O3 alloc_lottery.hip -o alloc_lottery && ./alloc_lottery
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #pragma clang diagnostic ignored "-Wunused-value"
 #pragma clang diagnostic ignored "-Wunused-result"
 
@@ -39,20 +40,21 @@ static float rate(const float *frames, float *out, long npix, long stride)
     return (float)((double)npix * 129 * 4 / (ms / 8) / 1e6);
 }
 
-int main()
+int main(int argc, char **argv)
 {
     const long npix = 4096L * 4096L, stride = npix + 16448;
     const size_t bytes = (size_t)stride * 128 * sizeof(float) + (8u << 20);
     float *out;
     hipMalloc(&out, npix * sizeof(float));
-    float *buf[8];
-    for (int i = 0; i < 8; i++) {
+    float *buf[28];
+    const int nalloc = argc > 1 ? atoi(argv[1]) : 8;
+    for (int i = 0; i < nalloc; i++) {
         if (hipMalloc(&buf[i], bytes) != hipSuccess) { printf("no memory at %d\n", i); return 1; }
         hipMemset(buf[i], 0, bytes);
     }
     hipDeviceSynchronize();
-    for (int round = 0; round < 3; round++)
-        for (int i = 0; i < 8; i++)
+    for (int round = 0; round < (nalloc > 8 ? 1 : 3); round++)
+        for (int i = 0; i < nalloc; i++)
             printf("round %d allocation %d at %p: %7.1f GB/s   base + 2 MiB: %7.1f   base + 64 KiB: %7.1f\n", round, i, (void *)buf[i],
                    rate(buf[i], out, npix, stride), rate(buf[i] + (2u << 20) / 4, out, npix, stride), rate(buf[i] + (64u << 10) / 4, out, npix, stride));
     return 0;

@@ -449,7 +449,7 @@ void stack_median_ml_kernel(StackArgs p)
     int N = p.n_frames;
     asm volatile("" : "+s"(N));
     float v[NS];
-    const int n = ml_gather_sorted<LPP, NS, false>(p.frames, p.stride, N, on, item, role, v);
+    const int n = ml_gather_sorted<LPP, NS, false, 16, 32, NS, NS / 2, NS, LPP == 2>(p.frames, p.stride, N, on, item, role, v);      // (nt loads at two lanes per pixel: fast_ml_common.hpp)
     const int kk = n >> 1;
     const float upper = pick_rank<LPP, NS, NS, NS>(v, kk, role, 0);
     const float lower = pick_rank<LPP, NS, NS, NS>(v, kk > 0 ? kk - 1 : 0, role, 0);

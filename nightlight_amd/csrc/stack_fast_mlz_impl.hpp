@@ -442,7 +442,7 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
 #ifdef NL_MLZ_HALVES             // (A/B builds: sort the first 64 positions while the other 64 loads are in flight -- 8 % slower)
         n = ml_gather_sort_halves<LPP, NS, (NTOP - 16) / LPP, NTOP / LPP>(p.frames, p.stride, N, on, pix, role, v);
 #else
-        n = ml_gather_raw<LPP, NS, (NTOP - 16) / LPP, NTOP / LPP>(p.frames, p.stride, N, on, pix, role, v);
+        n = ml_gather_raw<LPP, NS, (NTOP - 16) / LPP, NTOP / LPP, LPP == 2>(p.frames, p.stride, N, on, pix, role, v);      // (nt at two lanes per pixel: fast_ml_common.hpp)
 #if defined(NL_ROUND_STATS) && defined(NL_MLZ_EXP_TIMING)
         __builtin_amdgcn_sched_barrier(0); sp1 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -452,7 +452,7 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
 #endif
 #endif
     } else {
-        n = ml_gather_sorted<LPP, NS, L::FULL && !WINSOR, 32, 32, L::NSL, (NTOP - 16) / LPP, NTOP / LPP>(p.frames, p.stride, N, on, pix,
+        n = ml_gather_sorted<LPP, NS, L::FULL && !WINSOR, 32, 32, L::NSL, (NTOP - 16) / LPP, NTOP / LPP, LPP == 2 && !WINSOR>(p.frames, p.stride, N, on, pix,
                                                                                                               role, v);
     }
 

@@ -236,7 +236,7 @@ struct nl_stack {
     hipEvent_t ev_order[kOrderRing] = {};                   // nl_stack_order_stream_after
     int order_seq = 0;
     unsigned ev_rel = 0;                                   // creation flag of the pass's events (hipEventDisableSystemFence or 0)
-    float *d_frames_owned = nullptr;  // [n_frames][npix]
+    float *d_frames_owned = nullptr;  // [n_capacity][fstride_owned], the first npix floats of a slot in use
     float *d_frames = nullptr;        // owned or lent
     float *d_out = nullptr;           // [npix]
     float *d_acc = nullptr;           // stack-of-stacks accumulator, lazily allocated

@@ -15,7 +15,7 @@ constexpr int kClipSlots = 256;
 
 struct StackArgs {
     const float *frames;          // planar [n_frames][stride] fp32
-    int64_t stride;               // floats between consecutive frames (= tile pixels)
+    int64_t stride;               // floats between consecutive frames (>= tile pixels: the owned buffer is padded, nlstack_api.hip padded_frame_stride)
     int64_t npix;                 // pixels in the tile
     int64_t tiles;                // work items (wave tiles) in the launch
     int n_frames;

@@ -83,7 +83,7 @@ constexpr size_t kScratchBytes = sizeof(unsigned long long) * nl::kScratchWords;
 // The cgo drop-in creates a handle per OpStack.Apply (stack.go:131-138 allocates per call as well) and destroys it
 // afterwards: hipMalloc + hipFree of the frame buffer alone cost more than the headline pass (measured, bench.py
 // "fresh_handle": create 1.0 - 1.6 ms, destroy 1.3 - 1.8 ms, pass 1.7 ms).  The large buffers of a destroyed handle are
-// therefore parked -- at most kCacheBlocks of them, NL_MEM_CACHE_MB MiB in all (default: a sixteenth of the device's memory; 0 = off) -- and the
+// therefore parked -- per device at most kCacheBlocks of them and NL_MEM_CACHE_MB MiB (default: a sixteenth of the device's memory; 0 = off) -- and the
 // next handle with the same sizes on the same device takes them over.  nl_release_cached_memory() returns them to HIP.
 constexpr int kCacheBlocks = 16;
 constexpr size_t kCacheMinBytes = (size_t)1 << 20;
@@ -160,7 +160,12 @@ void cached_free(void *p, size_t bytes, int device)
     if (!p) return;
     if (bytes >= kCacheMinBytes) {
         std::lock_guard<std::mutex> lk(g_cache_mu);
-        if ((int)g_cache.size() < kCacheBlocks && g_cache_bytes + bytes <= cache_limit()) {
+        // (both limits per DEVICE: a group of one tile per GPU parks the buffers of all its tiles, nlstack_group.hip)
+        int blocks = 0;
+        size_t parked = 0;
+        for (const CachedBlock &b : g_cache)
+            if (b.device == device) { blocks++; parked += b.bytes; }
+        if (blocks < kCacheBlocks && parked + bytes <= cache_limit()) {
             g_cache.push_back({device, bytes, p});
             g_cache_bytes += bytes;
             return;

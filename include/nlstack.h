@@ -67,7 +67,7 @@ int nl_device_count(void);
 /* library version string */
 const char *nl_version(void);
 /* nl_stack_destroy parks the large device buffers of a handle (frames, result, hand-over lists, the scratch of the
- * winsorized / linear-fit cascades and of weighted passes; per device at most 16 blocks and NL_MEM_CACHE_MB MiB -- default:
+ * winsorized / linear-fit cascades and of weighted passes; per device at most 64 blocks and NL_MEM_CACHE_MB MiB -- default:
  * a sixteenth of the device's memory, 0 turns the cache off) for the next nl_stack_create / nl_group_create of the same
  * geometry on the same device: a drop-in that creates one handle per OpStack.Apply (stack.go:131-138 allocates per
  * call, too) otherwise pays more for hipMalloc + hipFree than for the stack pass.  This returns the parked buffers to

@@ -85,7 +85,7 @@ constexpr size_t kScratchBytes = sizeof(unsigned long long) * nl::kScratchWords;
 // "fresh_handle": create 1.0 - 1.6 ms, destroy 1.3 - 1.8 ms, pass 1.7 ms).  The large buffers of a destroyed handle are
 // therefore parked -- per device at most kCacheBlocks of them and NL_MEM_CACHE_MB MiB (default: a sixteenth of the device's memory; 0 = off) -- and the
 // next handle with the same sizes on the same device takes them over.  nl_release_cached_memory() returns them to HIP.
-constexpr int kCacheBlocks = 16;
+constexpr int kCacheBlocks = 64;
 constexpr size_t kCacheMinBytes = (size_t)1 << 20;
 struct CachedBlock { int device; size_t bytes; void *ptr; };
 std::mutex g_cache_mu;

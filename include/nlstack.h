@@ -74,6 +74,8 @@ const char *nl_version(void);
  * HIP.  The library does so itself whenever ANY of its own device allocations fails (every one of them goes through
  * one helper that releases the cache and retries); allocations of OTHER code in the process (torch, RCCL) do not see
  * the parked blocks as free memory -- call this, or set NL_MEM_CACHE_MB=0, when the process shares the device.
+ * The streams of destroyed handles are parked the same way (up to 32 idle streams per device: destroying a handle's two or
+ * three streams was 0.5 ms of its 0.55 ms, creating them 0.2 of 0.24) and destroyed here as well.
  * No counterpart in the reference. */
 void nl_release_cached_memory(void);
 

@@ -174,6 +174,51 @@ void cached_free(void *p, size_t bytes, int device)
     (void)hipFree(p);
 }
 
+// Streams are parked like the buffers: destroying the two or three streams of a handle is most of what nl_stack_destroy
+// costs once the buffers stay (tools/group_create_probe.py), and the drop-in makes a handle per Apply.  A parked stream is idle
+// (synchronised before it is parked); nl_release_cached_memory destroys them.
+constexpr size_t kStreamPool = 32;
+std::mutex g_stream_mu;
+std::vector<std::pair<int, hipStream_t>> g_streams;                // (device, non-blocking stream at default priority)
+
+hipError_t pooled_stream(hipStream_t *s, int device)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        for (size_t i = 0; i < g_streams.size(); i++)
+            if (g_streams[i].first == device) {
+                *s = g_streams[i].second;
+                g_streams.erase(g_streams.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
+void park_stream(hipStream_t s, int device)
+{
+    if (!s) return;
+    if (hipStreamSynchronize(s) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        size_t n = 0;
+        for (const auto &e : g_streams) n += e.first == device;
+        if (n < kStreamPool) { g_streams.emplace_back(device, s); return; }
+    } else {
+        (void)hipGetLastError();
+    }
+    (void)hipStreamDestroy(s);
+}
+
+void stream_pool_release_all()
+{
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (const auto &e : g_streams) { (void)hipSetDevice(e.first); (void)hipStreamDestroy(e.second); }
+    g_streams.clear();
+    (void)hipSetDevice(cur);
+}
+
 // ---- list-length hints across handles ---------------------------------------------------------------------------------
 // A pass sizes its replay grids and picks its protocol from the list lengths the last FINISHED pass on the handle
 // reported.  A handle that lives for one Apply never has one: its pass ran with 16 384-workgroup replay grids and the
@@ -370,7 +415,7 @@ const char *nl_version(void)
 #endif
 }
 
-void nl_release_cached_memory(void) { cache_release_all(); }
+void nl_release_cached_memory(void) { cache_release_all(); stream_pool_release_all(); }
 
 int nl_device_count(void)
 {
@@ -420,7 +465,7 @@ static int destroy_impl(nl_stack_t *h)
         if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
         if (h->stage_done[i]) (void)hipEventDestroy(h->stage_done[i]);
     }
-    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    park_stream(h->copy_stream, h->device);
     for (int i = 0; i < kTimingRing; i++) {
         if (h->ring_start[i]) (void)hipEventDestroy(h->ring_start[i]);
         if (h->ring_stop[i]) (void)hipEventDestroy(h->ring_stop[i]);
@@ -438,8 +483,8 @@ static int destroy_impl(nl_stack_t *h)
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (hipEvent_t &ev : h->ev_order) if (ev) (void)hipEventDestroy(ev);
-    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    park_stream(h->side_stream, h->device);
+    park_stream(h->stream, h->device);
     delete h;
     return NL_OK;
 }
@@ -456,10 +501,10 @@ static int create_impl(nl_stack_t *h)
     if (h->device < 0 || h->device >= ndev)
         return fail(NL_ERR_INVALID_ARG, "device %d out of range (have %d)", h->device, ndev);
     NL_HIP(hipSetDevice(h->device));
-    NL_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    NL_HIP(pooled_stream(&h->stream, h->device));
     // (the timing events of a ring slot are created by the first pass that uses it: a handle that lives for ONE
     // Apply -- the cgo drop-in -- creates 4 events instead of 256)
-    NL_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    NL_HIP(pooled_stream(&h->side_stream, h->device));
     {
         // Events that only order device work against device work (fork / join of the side stream) or only take times: no
         // system-scope fence when they complete (hipEventDisableSystemFence) -- the writeback / invalidate it stands for costs
@@ -579,7 +624,7 @@ int nl_stack_upload_tile(nl_stack_t *h, int idx, const float *host_tile)
 // the copy stream after the last operation that reads it).
 static int stage_host_bytes(nl_stack_t *h, const void *src_v, size_t bytes, char **staged, int *slot_out)
 {
-    if (!h->copy_stream) NL_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (!h->copy_stream) NL_HIP(pooled_stream(&h->copy_stream, h->device));
     if (h->pass_seq > 0 && h->copy_waits_pass != h->pass_seq) {
         // a pass enqueued earlier may still be reading the frames: the copy stream waits for its
         // end on the device (staging batch b+1 while batch b is stacked must not overwrite b)

@@ -12,6 +12,7 @@
 // nightlight_amd/dist.py.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <string>
 #include <thread>
@@ -23,6 +24,7 @@ struct nl_group {
     int n_frames = 0, width = 0, height = 0;
     std::vector<nl_stack_t *> tiles;
     std::vector<int> row0, rows;
+    int distinct_devices = 1;
 };
 
 extern "C" {
@@ -61,6 +63,16 @@ nl_group_t *nl_group_create(int n_frames, int width, int height, int n_tiles, co
         g->row0.push_back(r0);
         g->rows.push_back(nr);
     }
+    {
+        std::vector<int> seen;
+        for (int t = 0; t < n_tiles; t++) {
+            const int d = devices ? devices[t] : t % ndev;
+            bool have = false;
+            for (int s : seen) have = have || s == d;
+            if (!have) seen.push_back(d);
+        }
+        g->distinct_devices = (int)seen.size();
+    }
     return g;
 }
 
@@ -96,6 +108,14 @@ static int for_each_tile(nl_group_t *g, F &&f)
             return rc[t];
         }
     return NL_OK;
+}
+
+// The finish of a group pass on worker threads: when the tiles sit on more than one device (the copies of the result rows then
+// run over separate links); NL_GROUP_PARALLEL_FINISH=1 / 0 forces it on / off (the tests force it on one device).
+static bool finish_in_parallel(const nl_group_t *g)
+{
+    if (const char *e = getenv("NL_GROUP_PARALLEL_FINISH")) return e[0] == '1';
+    return g->distinct_devices > 1;
 }
 
 extern "C" {
@@ -190,6 +210,17 @@ int nl_group_run(nl_group_t *g, int mode, float sigma_low, float sigma_high, flo
         note(nl_stack_run_async(g->tiles[started], mode, sigma_low, sigma_high, ref_loc));
     if (first_rc != NL_OK) started--;                     // (nl_stack_run_async settles a handle whose pass failed: nothing of it is in flight)
     int64_t lo = 0, hi = 0;
+    if (first_rc == NL_OK && finish_in_parallel(g)) {
+        // one host thread per tile: a tile's finish is a wait and the copy of its rows into the caller's (pageable) buffer --
+        // 8 MiB of a 4096 x 4096 result per tile of eight, each over its own device's link
+        std::vector<int64_t> l(g->tiles.size(), 0), h(g->tiles.size(), 0);
+        const int rc = for_each_tile(g, [&](size_t t) { return nl_stack_finish(g->tiles[t], out_host, &l[t], &h[t]); });
+        if (rc != NL_OK) return rc;                       // (for_each_tile finished every tile and kept the first message)
+        for (size_t t = 0; t < g->tiles.size(); t++) { lo += l[t]; hi += h[t]; }
+        if (clip_low) *clip_low = lo;
+        if (clip_high) *clip_high = hi;
+        return NL_OK;
+    }
     for (size_t t = 0; t < started; t++) {
         int64_t l = 0, h = 0;
         note(nl_stack_finish(g->tiles[t], first_rc == NL_OK ? out_host : nullptr, &l, &h));

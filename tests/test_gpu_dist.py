@@ -122,6 +122,29 @@ def test_group_fans_one_stack_out_over_tiles(nl, oracle, tiles):
         assert bits_equal(acc, oracle.stack_incremental_finalize(a, 5.0))
 
 
+@pytest.mark.parametrize("tiles", [2, 5])
+def test_group_finish_on_worker_threads_gives_the_serial_result(nl, oracle, monkeypatch, tiles):
+    # nl_group_run finishes its tiles on worker threads when they sit on several devices (the copies of the result rows then
+    # run over separate links); forced here on one device, against the serial finish and the oracle
+    frames = make_frames(N, W, H, seed=7300 + tiles)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("NL_GROUP_PARALLEL_FINISH", flag)
+        with nl.StackGroup(N, W, H, devices=[0] * tiles) as g:
+            g.upload_frames(frames)
+            res[flag] = [g.run(mode, 2.0, 2.5) for mode in (1, 2, 3, 5)]
+            g.set_weights(np.ones(N, np.float32))
+            with pytest.raises(Exception):
+                g.run(4)                                     # (a failing pass leaves nothing pending in either flavour)
+            g.set_weights(None)
+            again = g.run(2, 2.0, 2.5)
+            assert again[1:] == res[flag][1][1:] and bits_equal(again[0], res[flag][1][0])
+    for (a, al, ah), (b, bl, bh) in zip(res["0"], res["1"]):
+        assert (al, ah) == (bl, bh) and bits_equal(a, b)
+    rc, want, wl, wh, _ = oracle.stack_apply(2, frames, None, 2.0, 2.5)
+    assert rc == 0 and res["1"][1][1:] == (wl, wh)
+
+
 def test_group_errors_follow_the_handle(nl):
     from nightlight_amd import capi
     with nl.StackGroup(4, 32, 16, devices=[0, 0]) as g:

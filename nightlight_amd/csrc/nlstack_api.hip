@@ -357,6 +357,36 @@ struct nl_stack {
     const char *last_kernel = "";
 };
 
+// stats.MeanStdDev over xs = 0..n-1 (stats.go:246-261, called from :570) depends on n only: tabulated once per frame count
+// of the process, in the same fp32 operation order ({mean, stddev} for n = 1 .. n_frames at [2n], [2n + 1]).  (The table is
+// O(n^2) scalar operations: 0.45 ms of a 512-frame handle's create.)  Returned by value: 8 bytes per frame.
+static std::vector<float> xstat_table(int n_frames)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, std::vector<float>>> tables;        // (a handful of frame counts per process)
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto &t : tables)
+        if (t.first == n_frames) return t.second;
+    std::vector<float> xstat(2 * (size_t)(n_frames + 1), 0.0f);
+    for (int n = 1; n <= n_frames; n++) {
+        volatile float s = 0.0f;
+        for (int i = 0; i < n; i++) s = s + (float)i;
+        const float mean = s / (float)n;
+        volatile float v = 0.0f;
+        for (int i = 0; i < n; i++) {
+            volatile float d = (float)i - mean;
+            volatile float dd = d * d;
+            v = v + dd;
+        }
+        const float var = v / (float)n;
+        xstat[2 * (size_t)n] = mean;
+        xstat[2 * (size_t)n + 1] = (float)sqrt((double)var);
+    }
+    if (tables.size() >= 64) tables.erase(tables.begin());
+    tables.emplace_back(n_frames, xstat);
+    return xstat;
+}
+
 // Floats between consecutive frames of the owned planar buffer.  A stride that is a multiple of a large power of two
 // -- 4096 x 4096 floats = 2^26 bytes, or a 512-row tile's 2^23 -- puts the same pixel of every frame into the same
 // HBM channel / bank: the 4 frames one load of the LDS-column kernels reads, and the 128-512 loads a wave has in
@@ -537,23 +567,7 @@ static int create_impl(nl_stack_t *h)
     NL_HIP(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * 4, h->stream));
     NL_HIP(dev_malloc(&h->d_stat_partial, sizeof(double) * 3 * kStatBlocks));
 
-    // stats.MeanStdDev over xs = 0..n-1 (stats.go:246-261, called from :570)
-    // depends on n only: tabulate it once, in the same fp32 operation order.
-    std::vector<float> xstat(2 * (size_t)(h->n_frames + 1), 0.0f);
-    for (int n = 1; n <= h->n_frames; n++) {
-        volatile float s = 0.0f;
-        for (int i = 0; i < n; i++) s = s + (float)i;
-        const float mean = s / (float)n;
-        volatile float v = 0.0f;
-        for (int i = 0; i < n; i++) {
-            volatile float d = (float)i - mean;
-            volatile float dd = d * d;
-            v = v + dd;
-        }
-        const float var = v / (float)n;
-        xstat[2 * (size_t)n] = mean;
-        xstat[2 * (size_t)n + 1] = (float)sqrt((double)var);
-    }
+    const std::vector<float> xstat = xstat_table(h->n_frames);
     NL_HIP(dev_malloc(&h->d_xstat, xstat.size() * sizeof(float)));
     NL_HIP(hipMemcpy(h->d_xstat, xstat.data(), xstat.size() * sizeof(float), hipMemcpyHostToDevice));
     return NL_OK;

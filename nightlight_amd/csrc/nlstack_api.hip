@@ -165,7 +165,8 @@ void cached_free(void *p, size_t bytes, int device)
         size_t parked = 0;
         for (const CachedBlock &b : g_cache)
             if (b.device == device) { blocks++; parked += b.bytes; }
-        if (blocks < kCacheBlocks && parked + bytes <= cache_limit()) {
+        static const int max_blocks = [] { const char *e = getenv("NL_CACHE_BLOCKS"); return e ? atoi(e) : kCacheBlocks; }();
+        if (blocks < max_blocks && parked + bytes <= cache_limit()) {
             g_cache.push_back({device, bytes, p});
             g_cache_bytes += bytes;
             return;
@@ -177,34 +178,85 @@ void cached_free(void *p, size_t bytes, int device)
 // Streams are parked like the buffers: destroying the two or three streams of a handle is most of what nl_stack_destroy
 // costs once the buffers stay (tools/group_create_probe.py), and the drop-in makes a handle per Apply.  A parked stream is idle
 // (synchronised before it is parked); nl_release_cached_memory destroys them.
+// A stream keeps its ROLE (round 6): HIP binds a stream to one of its few hardware queues when it is created, and the main and
+// side stream of a handle -- created back to back -- sit on different ones, which is what lets the replay of a pass run beside its
+// generic pass.  Round 5 parked all streams in one list: the next handle's main stream could be a former copy stream (created
+// lazily, any queue) next to a former side stream on the SAME queue, and the tail of every pass with a long replay serialised
+// (C3 tile 4.10 -> 4.58 ms, winsor 24 2.65 -> 2.88, tools/bisect_tail.sh, profiles/r06_bisect_tail.txt).  Main + side are
+// therefore parked and handed out as the PAIR they were created as; copy streams have a list of their own.
+// NL_STREAM_POOL=0 turns the pool off.
 constexpr size_t kStreamPool = 32;
+struct StreamPair { int device; hipStream_t main, side; };
 std::mutex g_stream_mu;
-std::vector<std::pair<int, hipStream_t>> g_streams;                // (device, non-blocking stream at default priority)
+std::vector<StreamPair> g_stream_pairs;
+std::vector<std::pair<int, hipStream_t>> g_copy_streams;           // (device, non-blocking stream at default priority)
 
-hipError_t pooled_stream(hipStream_t *s, int device)
+bool stream_pool_on()
 {
-    {
+    static const bool on = [] { const char *e = getenv("NL_STREAM_POOL"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
+hipError_t pooled_stream_pair(hipStream_t *main, hipStream_t *side, int device)
+{
+    if (stream_pool_on()) {
         std::lock_guard<std::mutex> lk(g_stream_mu);
-        for (size_t i = 0; i < g_streams.size(); i++)
-            if (g_streams[i].first == device) {
-                *s = g_streams[i].second;
-                g_streams.erase(g_streams.begin() + (long)i);
+        for (size_t i = g_stream_pairs.size(); i-- > 0;)
+            if (g_stream_pairs[i].device == device) {
+                *main = g_stream_pairs[i].main;
+                *side = g_stream_pairs[i].side;
+                g_stream_pairs.erase(g_stream_pairs.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    hipError_t e = hipStreamCreateWithFlags(main, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+    e = hipStreamCreateWithFlags(side, hipStreamNonBlocking);
+    if (e != hipSuccess) { (void)hipStreamDestroy(*main); *main = nullptr; }
+    return e;
+}
+
+hipError_t pooled_copy_stream(hipStream_t *s, int device)
+{
+    if (stream_pool_on()) {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        for (size_t i = g_copy_streams.size(); i-- > 0;)
+            if (g_copy_streams[i].first == device) {
+                *s = g_copy_streams[i].second;
+                g_copy_streams.erase(g_copy_streams.begin() + (long)i);
                 return hipSuccess;
             }
     }
     return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
 
-void park_stream(hipStream_t s, int device)
+static bool stream_idle(hipStream_t s)
 {
-    if (!s) return;
-    if (hipStreamSynchronize(s) == hipSuccess) {
+    if (hipStreamSynchronize(s) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+}
+
+void park_stream_pair(hipStream_t main, hipStream_t side, int device)
+{
+    if (main && side && stream_pool_on() && stream_idle(side) && stream_idle(main)) {
         std::lock_guard<std::mutex> lk(g_stream_mu);
         size_t n = 0;
-        for (const auto &e : g_streams) n += e.first == device;
-        if (n < kStreamPool) { g_streams.emplace_back(device, s); return; }
-    } else {
-        (void)hipGetLastError();
+        for (const auto &e : g_stream_pairs) n += e.device == device;
+        if (n < kStreamPool / 2) { g_stream_pairs.push_back({device, main, side}); return; }
+    }
+    if (side) (void)hipStreamDestroy(side);
+    if (main) (void)hipStreamDestroy(main);
+}
+
+void park_copy_stream(hipStream_t s, int device)
+{
+    if (!s) return;
+    if (stream_pool_on() && stream_idle(s)) {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        size_t n = 0;
+        for (const auto &e : g_copy_streams) n += e.first == device;
+        if (n < kStreamPool / 2) { g_copy_streams.emplace_back(device, s); return; }
     }
     (void)hipStreamDestroy(s);
 }
@@ -214,8 +266,10 @@ void stream_pool_release_all()
     std::lock_guard<std::mutex> lk(g_stream_mu);
     int cur = 0;
     (void)hipGetDevice(&cur);
-    for (const auto &e : g_streams) { (void)hipSetDevice(e.first); (void)hipStreamDestroy(e.second); }
-    g_streams.clear();
+    for (const auto &e : g_copy_streams) { (void)hipSetDevice(e.first); (void)hipStreamDestroy(e.second); }
+    g_copy_streams.clear();
+    for (const auto &e : g_stream_pairs) { (void)hipSetDevice(e.device); (void)hipStreamDestroy(e.side); (void)hipStreamDestroy(e.main); }
+    g_stream_pairs.clear();
     (void)hipSetDevice(cur);
 }
 
@@ -495,7 +549,7 @@ static int destroy_impl(nl_stack_t *h)
         if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
         if (h->stage_done[i]) (void)hipEventDestroy(h->stage_done[i]);
     }
-    park_stream(h->copy_stream, h->device);
+    park_copy_stream(h->copy_stream, h->device);
     for (int i = 0; i < kTimingRing; i++) {
         if (h->ring_start[i]) (void)hipEventDestroy(h->ring_start[i]);
         if (h->ring_stop[i]) (void)hipEventDestroy(h->ring_stop[i]);
@@ -513,8 +567,7 @@ static int destroy_impl(nl_stack_t *h)
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (hipEvent_t &ev : h->ev_order) if (ev) (void)hipEventDestroy(ev);
-    park_stream(h->side_stream, h->device);
-    park_stream(h->stream, h->device);
+    park_stream_pair(h->stream, h->side_stream, h->device);
     delete h;
     return NL_OK;
 }
@@ -531,10 +584,10 @@ static int create_impl(nl_stack_t *h)
     if (h->device < 0 || h->device >= ndev)
         return fail(NL_ERR_INVALID_ARG, "device %d out of range (have %d)", h->device, ndev);
     NL_HIP(hipSetDevice(h->device));
-    NL_HIP(pooled_stream(&h->stream, h->device));
+    // (main and side stream as the pair they were created as: different hardware queues, see the stream pool)
+    NL_HIP(pooled_stream_pair(&h->stream, &h->side_stream, h->device));
     // (the timing events of a ring slot are created by the first pass that uses it: a handle that lives for ONE
     // Apply -- the cgo drop-in -- creates 4 events instead of 256)
-    NL_HIP(pooled_stream(&h->side_stream, h->device));
     {
         // Events that only order device work against device work (fork / join of the side stream) or only take times: no
         // system-scope fence when they complete (hipEventDisableSystemFence) -- the writeback / invalidate it stands for costs
@@ -638,7 +691,7 @@ int nl_stack_upload_tile(nl_stack_t *h, int idx, const float *host_tile)
 // the copy stream after the last operation that reads it).
 static int stage_host_bytes(nl_stack_t *h, const void *src_v, size_t bytes, char **staged, int *slot_out)
 {
-    if (!h->copy_stream) NL_HIP(pooled_stream(&h->copy_stream, h->device));
+    if (!h->copy_stream) NL_HIP(pooled_copy_stream(&h->copy_stream, h->device));
     if (h->pass_seq > 0 && h->copy_waits_pass != h->pass_seq) {
         // a pass enqueued earlier may still be reading the frames: the copy stream waits for its
         // end on the device (staging batch b+1 while batch b is stacked must not overwrite b)

@@ -13,6 +13,7 @@
 #include <float.h>
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -752,6 +753,41 @@ static void run_batch(apply_job *job, int64_t lower, int64_t upper,
     }
 }
 
+/* Timing aid (bench.py cpu_baseline, tools/cpu_probe.py): worker t of the pool is pinned to the t-th CPU of the
+ * process's affinity mask, so that a measurement does not depend on how fast the scheduler spreads freshly created
+ * threads (Go's runtime keeps GOMAXPROCS long-lived OS threads that are spread already).  Results never depend on it. */
+static int g_pin_workers = 0;
+void nlo_set_pin_workers(int on) { g_pin_workers = on; }
+
+static void pin_worker(int t)
+{
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    int n = CPU_COUNT(&allowed);
+    if (n <= 0) return;
+    int want = t % n, seen = 0;
+    for (int c = 0; c < CPU_SETSIZE; c++) {
+        if (!CPU_ISSET(c, &allowed)) continue;
+        if (seen++ == want) {
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            CPU_SET(c, &one);
+            (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+            return;
+        }
+    }
+}
+
+typedef struct { void *job; int index; } worker_arg;
+
+static void *apply_worker(void *arg);
+static void *apply_worker_pinned(void *arg)
+{
+    worker_arg *wa = (worker_arg *)arg;
+    pin_worker(wa->index);
+    return apply_worker(wa->job);
+}
+
 static void *apply_worker(void *arg)
 {
     apply_job *job = (apply_job *)arg;
@@ -808,8 +844,14 @@ int nlo_stack_apply(int mode, const float *const *lights, const float *weights,
         apply_worker(&job);
     } else {
         pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)num_cpu);
-        for (int t = 0; t < num_cpu; t++) pthread_create(&th[t], NULL, apply_worker, &job);
+        worker_arg *wa = (worker_arg *)malloc(sizeof(worker_arg) * (size_t)num_cpu);
+        for (int t = 0; t < num_cpu; t++) {
+            wa[t].job = &job; wa[t].index = t;
+            if (g_pin_workers) pthread_create(&th[t], NULL, apply_worker_pinned, &wa[t]);
+            else pthread_create(&th[t], NULL, apply_worker, &job);
+        }
         for (int t = 0; t < num_cpu; t++) pthread_join(th[t], NULL);
+        free(wa);
         free(th);
     }
     pthread_mutex_destroy(&job.lock);

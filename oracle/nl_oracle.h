@@ -130,6 +130,8 @@ int  nlo_auto_select_mode(int n_frames);
  * weights_out must hold n_frames floats; *has_weights is 0 for mode none. */
 int  nlo_get_weights(int weighting, const float *per_frame, int n_frames,
                      float *weights_out, int *has_weights, int *bad_index);
+/* timing aid: pin worker t of nlo_stack_apply's pool to the t-th allowed CPU (0 = off, the default) */
+void nlo_set_pin_workers(int on);
 /* OpStack.Apply: mode (0..6), optional weights (NULL = none), batching rule
  * numBatches=max(4*N*P/8MiB, 8*num_cpu), num_cpu worker threads. */
 int  nlo_stack_apply(int mode, const float *const *lights, const float *weights,

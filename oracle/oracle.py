@@ -90,6 +90,8 @@ def lib():
                                       C.c_float, C.c_float, C.c_int, _f32p, _i64p, _i64p,
                                       C.POINTER(C.c_int)]
         L.nlo_stack_apply.restype = C.c_int
+        L.nlo_set_pin_workers.argtypes = [C.c_int]
+        L.nlo_set_pin_workers.restype = None
         _u8p = C.POINTER(C.c_ubyte)
         L.nlo_fits_decode.argtypes = [_u8p, C.c_int, C.c_int64, C.c_float, C.c_float, _f32p, _f32p, _f32p, _f32p]
         L.nlo_fits_decode.restype = C.c_int
@@ -255,6 +257,11 @@ def stack_apply(mode, frames, weights=None, sigma_low=2.75, sigma_high=2.75,
                                C.c_float(sigma_low), C.c_float(sigma_high), int(num_cpu),
                                _fp(res), C.byref(cl), C.byref(ch), C.byref(mu))
     return rc, res, cl.value, ch.value, mu.value
+
+
+def set_pin_workers(on):
+    """Timing aid: pin the workers of stack_apply's pool to the allowed CPUs (results never depend on it)."""
+    lib().nlo_set_pin_workers(1 if on else 0)
 
 
 def stack_incremental(stack, light, weight, first):

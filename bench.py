@@ -70,7 +70,9 @@ def parse():
                     help="1-GPU runs only: height of the whole image the --height rows tile is cut from")
     ap.add_argument("--cpu-rows", type=int, default=0,
                     help="rows of the stack timed on the CPU (0 = auto, about 3 s per run)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the host-side legs: cpu_baseline and apply_from_host")
+    ap.add_argument("--apply", action="store_true", help="run the apply_from_host leg even with --no-cpu")
+    ap.add_argument("--no-apply", action="store_true", help="skip the apply_from_host leg (OpStack.Apply from host memory)")
     ap.add_argument("--preheat-steps", type=int, default=64,
                     help="untimed passes in front of the W warm-up steps (the same number on every rank): a box fresh from idle "
                          "runs its first ~30 ms of work at a lower clock and 5 warm-up passes are 9 ms -- measured 1.91 ms per pass "
@@ -196,6 +198,92 @@ def cpu_baseline(st, args, rows, weights=None, frames_n=None, mode=None, width=N
                       "(%d usable%s; %d hardware threads, %d physical cores of %s)"
                       % (rows, w, n, MODE_NAMES[mode], dt, c_best, usable,
                          (" -- " + limit) if limit else "", threads, physical, model)}, res, cc
+
+
+PCIE_GEN5_X16_GIBS = 63.0 * 1e9 / 1024.0 ** 3          # 32 GT/s x 16 lanes, 128b/130b: 63.0 GB/s per direction before packet overhead
+
+
+def apply_from_host(st, n, w, h, mode, kappa, device, want_result, want_counters):
+    """What a Nightlight user waits for: OpStack.Apply (stack.go:115-227) from frames in HOST memory,
+    through exactly the calls go/stackhip/stack_hip.go:92-121 makes -- nl_group_create, nl_group_upload_frame x N,
+    nl_group_set_weights, nl_group_run (result into a host buffer), nl_group_destroy -- on ONE GPU.  Frames are N pageable,
+    separately allocated host arrays (as fits.Image.Data is), first-touched by worker threads, holding the resident synthetic
+    stack of `st` (so the result can be checked against the resident pass).  Two legs: fp32 frames, and the int16 FITS payload
+    path (nl_group_upload_frame_fits: big-endian BITPIX 16 / BZERO 32768 as cameras write it, half the PCIe bytes, decoded on
+    the device).  Each leg runs twice (a process's first Apply pays hipHostMalloc of the staging ring and cold buffers);
+    the second is reported, the first kept as "first_apply_of_the_process".  Breakdown: create, the upload calls (host staging
+    memcpy + DMA issue, overlapped), nl_group_run (tail of the DMAs + pass + 64 MiB result download), destroy; a second
+    nl_group_run on the settled group separates pass + download from the upload tail."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from nightlight_amd import StackGroup
+    from tools.cpu_probe import host_limits
+    usable = host_limits()["usable_threads"]
+    gib = 1024.0 ** 3
+    frames = [None] * n
+    with ThreadPoolExecutor(max(1, min(usable, 16))) as ex:
+        futs = []
+        for i in range(n):
+            tmp = st.download_tile(i)
+            futs.append(ex.submit(lambda i=i, tmp=tmp: frames.__setitem__(i, tmp.copy())))
+        for f in futs:
+            f.result()
+        # int16 payloads: 8 distinct quantised frames, copied into N separate allocations
+        def payload(i):
+            q = np.clip(np.rint(np.nan_to_num(frames[i], nan=0.0)), 0, 65535).astype(np.int32) - 32768
+            return np.frombuffer(q.astype(">i2").tobytes(), np.uint8)
+        distinct = list(ex.map(payload, range(min(8, n))))
+        raws = list(ex.map(lambda i: distinct[i % len(distinct)].copy(), range(n)))
+
+    def one(kind):
+        t0 = time.perf_counter()
+        g = StackGroup(n, w, h, devices=[device])
+        t1 = time.perf_counter()
+        for i in range(n):
+            if kind == "fp32":
+                g.upload_frame(i, frames[i])
+            else:
+                g.upload_frame_fits(i, raws[i], 16, 1.0, 32768.0)
+        g.set_weights(None)
+        t2 = time.perf_counter()
+        out, cl, ch = g.run(mode, kappa, kappa, 0.0)
+        t3 = time.perf_counter()
+        out2, _, _ = g.run(mode, kappa, kappa, 0.0)              # settled group: pass + download only
+        t4 = time.perf_counter()
+        pass_ms = g.tile(0).pass_times(0)[0]
+        g.close()
+        t5 = time.perf_counter()
+        nbytes = n * w * h * (4 if kind == "fp32" else 2)
+        resident_ms = (t4 - t3) * 1e3
+        run_ms = (t3 - t2) * 1e3
+        upload_s = (t2 - t1) + max(0.0, run_ms - resident_ms) / 1e3
+        wall_ms = ((t3 - t0) + (t5 - t4)) * 1e3                    # create + uploads + run + destroy (the extra run excluded)
+        r = {"wall_ms": round(wall_ms, 2), "ms_create": round((t1 - t0) * 1e3, 3),
+             "ms_upload_calls": round((t2 - t1) * 1e3, 2), "ms_run": round(run_ms, 2),
+             "ms_run_on_settled_group": round(resident_ms, 2), "ms_pass_device": round(pass_ms, 3),
+             "ms_result_download": round(resident_ms - pass_ms, 2), "ms_upload_tail_in_run": round(max(0.0, run_ms - resident_ms), 2),
+             "ms_destroy": round((t5 - t4) * 1e3, 3),
+             "host_bytes": nbytes, "upload_gib_s": round(nbytes / gib / upload_s, 2),
+             "upload_frac_of_pcie_gen5_x16": round(nbytes / gib / upload_s / PCIE_GEN5_X16_GIBS, 3),
+             "mpixels_per_s_end_to_end": round(w * h / (wall_ms * 1e-3) / 1e6, 2),
+             "share": {"upload": round(upload_s * 1e3 / wall_ms, 3), "pass": round(pass_ms / wall_ms, 4),
+                       "download": round((resident_ms - pass_ms) / wall_ms, 4),
+                       "create_destroy": round(((t1 - t0) + (t5 - t4)) * 1e3 / wall_ms, 4)},
+             "clip_counters": [int(cl), int(ch)]}
+        return r, out
+
+    res = {"note": "OpStack.Apply from host memory on 1 GPU: nl_group_create / nl_group_upload_frame x %d / nl_group_run / "
+                   "nl_group_destroy as go/stackhip/stack_hip.go calls them; %d pageable, separately allocated frames of "
+                   "%d x %d; pcie peak = Gen5 x16 %.1f GiB/s" % (n, n, h, w, PCIE_GEN5_X16_GIBS)}
+    for kind in ("fp32", "fits_int16"):
+        first, _ = one(kind)
+        second, out = one(kind)
+        second["first_apply_of_the_process"] = {k: first[k] for k in ("wall_ms", "ms_create", "ms_upload_calls", "ms_run", "ms_destroy", "upload_gib_s")}
+        if kind == "fp32":
+            second["result_equals_resident_pass"] = bool(np.array_equal(out, want_result, equal_nan=True))
+            second["counters_equal_resident_pass"] = bool(tuple(second["clip_counters"]) == tuple(want_counters))
+        res[kind] = second
+    return res
 
 
 def measured_traffic(kernel, frames, width, rows, mode):
@@ -524,6 +612,9 @@ def main():
                     c = fresh_handle_cost(st, n, m_, wt_)
                     out["fresh_handle"][tag] = {k: c[k] for k in ("ms_create", "ms_first_pass_fresh_handle", "ms_destroy", "ms_create_destroy")}
 
+    if rank == 0 and world == 1 and dist is None and default_workload_early and (args.apply or not (args.no_apply or args.no_cpu)):     # (--no-cpu skips both host-side legs)
+        want = st.download_rows(-1, 0, rows)          # result of the last resident pass (same frames, same kappa)
+        out["apply_from_host"] = apply_from_host(st, n, w, image_rows, args.mode, args.kappa, device, want, (cl, ch))
     st.close()
     # The other stack depths the north star names (4096 x 4096 x {32, 512} fp32, sigma clipping), same protocol
     # and the same row tiles, reported beside the headline (which stays what `value` is).

@@ -175,6 +175,57 @@ void cached_free(void *p, size_t bytes, int device)
     (void)hipFree(p);
 }
 
+// Pinned staging buffers are parked as well (round 6): a handle per Apply allocated its ring of kStageSlots pinned buffers
+// inside its first uploads and freed it in destroy -- hipHostMalloc + hipHostFree of 4 x 64 MiB are 10 + 10 ms of the 180 ms an
+// Apply of 128 frames from host memory takes (bench.py apply_from_host).  At most kPinnedBlocks blocks / kPinnedLimit bytes
+// stay (process-wide: pinned memory belongs to no device); a request takes the smallest parked block that is large enough.
+constexpr size_t kPinnedBlocks = 16;
+constexpr size_t kPinnedLimit = (size_t)2 << 30;
+std::mutex g_pinned_mu;
+std::vector<std::pair<size_t, void *>> g_pinned;
+size_t g_pinned_bytes = 0;
+
+hipError_t pinned_malloc(void **p, size_t bytes, size_t *cap)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        size_t best = g_pinned.size();
+        for (size_t i = 0; i < g_pinned.size(); i++)
+            if (g_pinned[i].first >= bytes && (best == g_pinned.size() || g_pinned[i].first < g_pinned[best].first)) best = i;
+        if (best < g_pinned.size() && g_pinned[best].first <= 2 * bytes + ((size_t)1 << 20)) {
+            *p = g_pinned[best].second;
+            *cap = g_pinned[best].first;
+            g_pinned_bytes -= g_pinned[best].first;
+            g_pinned.erase(g_pinned.begin() + (long)best);
+            return hipSuccess;
+        }
+    }
+    *cap = bytes;
+    return hipHostMalloc(p, bytes, hipHostMallocDefault);
+}
+
+void pinned_free(void *p, size_t cap)
+{
+    if (!p) return;
+    if (cache_limit() > 0) {                               // (NL_MEM_CACHE_MB=0 turns every cache of the library off)
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        if (g_pinned.size() < kPinnedBlocks && g_pinned_bytes + cap <= kPinnedLimit) {
+            g_pinned.emplace_back(cap, p);
+            g_pinned_bytes += cap;
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+}
+
+void pinned_release_all()
+{
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    for (const auto &e : g_pinned) (void)hipHostFree(e.second);
+    g_pinned.clear();
+    g_pinned_bytes = 0;
+}
+
 // Streams are parked like the buffers: destroying the two or three streams of a handle is most of what nl_stack_destroy
 // costs once the buffers stay (tools/group_create_probe.py), and the drop-in makes a handle per Apply.  A parked stream is idle
 // (synchronised before it is parked); nl_release_cached_memory destroys them.
@@ -499,7 +550,7 @@ const char *nl_version(void)
 #endif
 }
 
-void nl_release_cached_memory(void) { cache_release_all(); stream_pool_release_all(); }
+void nl_release_cached_memory(void) { cache_release_all(); stream_pool_release_all(); pinned_release_all(); }
 
 int nl_device_count(void)
 {
@@ -546,7 +597,7 @@ static int destroy_impl(nl_stack_t *h)
     if (h->d_lf_count) (void)hipFree(h->d_lf_count);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     for (int i = 0; i < kStageSlots; i++) {
-        if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
+        pinned_free(h->h_stage[i], h->stage_cap[i]);
         if (h->stage_done[i]) (void)hipEventDestroy(h->stage_done[i]);
     }
     park_copy_stream(h->copy_stream, h->device);
@@ -703,9 +754,8 @@ static int stage_host_bytes(nl_stack_t *h, const void *src_v, size_t bytes, char
     if (h->stage_used[slot]) NL_HIP(hipEventSynchronize(h->stage_done[slot]));     // its last DMA has left the buffer
     if (!h->stage_done[slot]) NL_HIP(hipEventCreateWithFlags(&h->stage_done[slot], hipEventDisableTiming));
     if (h->stage_cap[slot] < bytes) {
-        if (h->h_stage[slot]) { NL_HIP(hipHostFree(h->h_stage[slot])); h->h_stage[slot] = nullptr; h->stage_cap[slot] = 0; }
-        NL_HIP(hipHostMalloc(&h->h_stage[slot], bytes, hipHostMallocDefault));
-        h->stage_cap[slot] = bytes;
+        if (h->h_stage[slot]) { pinned_free(h->h_stage[slot], h->stage_cap[slot]); h->h_stage[slot] = nullptr; h->stage_cap[slot] = 0; }
+        NL_HIP(pinned_malloc(&h->h_stage[slot], bytes, &h->stage_cap[slot]));
     }
     const char *src = static_cast<const char *>(src_v);
     char *dst = static_cast<char *>(h->h_stage[slot]);
@@ -746,6 +796,8 @@ int nl_stack_upload_frame_async(nl_stack_t *h, int idx, const float *host_frame)
     int slot = 0;
     int rc = stage_host_bytes(h, host_frame + (int64_t)h->row0 * h->width, bytes, &dst, &slot);
     if (rc != NL_OK) return rc;
+    // (fp32 frames keep the copy engine: a kernel that pulls the frame out of the pinned buffer itself, as the FITS decode
+    // below does, measured 41.6 against 43.3 GiB/s on the same box -- profiles/r06_apply_from_host.txt)
     NL_HIP(hipMemcpyAsync(h->d_frames + (int64_t)idx * h->fstride, dst, bytes, hipMemcpyHostToDevice, h->copy_stream));
     return stage_done(h, slot);
 }
@@ -2235,11 +2287,23 @@ int nl_stack_upload_frame_fits_async(nl_stack_t *h, int idx, const void *raw_hos
     int slot = 0;
     int rc = stage_host_bytes(h, raw_host, bytes, &staged, &slot);
     if (rc != NL_OK) return rc;
-    rc = ingest_async_reserve(h, bytes);
-    if (rc != NL_OK) return rc;
-    NL_HIP(hipMemcpyAsync(h->d_ingest_async, staged, bytes, hipMemcpyHostToDevice, h->copy_stream));
+    // The decode kernel reads the payload straight out of the pinned staging buffer (round 6): DMA into a device scratch
+    // and a kernel behind it on one stream took turns -- copy engine, compute queue, copy engine ... with a dependency
+    // hand-over each way -- and ran at 0.9 ms per 32 MiB int16 frame where the link needs 0.6 (bench.py apply_from_host:
+    // 34.7 GiB/s).  One kernel per frame that pulls its bytes over the link in 16-byte loads has no hand-over at all.
+    // NL_FITS_ZEROCOPY=0: the DMA + kernel pair, for A/B runs.
+    static const bool zero_copy = [] { const char *e = getenv("NL_FITS_ZEROCOPY"); return !e || atoi(e) != 0; }();
+    const void *raw_dev = staged;
+    if (!zero_copy) {
+        rc = ingest_async_reserve(h, bytes);
+        if (rc != NL_OK) return rc;
+        NL_HIP(hipMemcpyAsync(h->d_ingest_async, staged, bytes, hipMemcpyHostToDevice, h->copy_stream));
+        raw_dev = h->d_ingest_async;
+    } else if (!h->d_stat_partial_async) {
+        NL_HIP(dev_malloc(&h->d_stat_partial_async, sizeof(double) * 3 * kStatBlocks));
+    }
     const bool affine = !(multiplier == 1.0f && offset == 0.0f);
-    NL_HIP(nl::launch_fits_decode(h->d_ingest_async, bitpix, h->npix, bscale, bzero, affine, multiplier, offset,
+    NL_HIP(nl::launch_fits_decode(raw_dev, bitpix, h->npix, bscale, bzero, affine, multiplier, offset,
                                   h->d_frames + (int64_t)idx * h->fstride, h->d_stat_partial_async, kStatBlocks,
                                   h->copy_stream));
     return stage_done(h, slot);

@@ -48,7 +48,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MODE_NAMES = {0: "median", 1: "mean", 2: "sigma-clip", 3: "winsorized sigma-clip",
               4: "MAD sigma-clip", 5: "linear-fit"}
-TRAFFIC_FILES = ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0      # wave-instructions/s: 1024 SIMDs, one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md), 2.4 GHz
+TRAFFIC_FILES = ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
 
 
 def parse():
@@ -286,11 +287,12 @@ def apply_from_host(st, n, w, h, mode, kappa, device, want_result, want_counters
     return res
 
 
-def measured_traffic(kernel, frames, width, rows, mode):
+def measured_traffic(kernel, frames, width, rows, mode, want_issue=False):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
     (profiles/rNN_traffic.json: FETCH_SIZE / WRITE_SIZE with the guide's gfx950
     corrections; newest round first), or (None, None) when this workload -- this kernel at
-    this geometry -- was not profiled."""
+    this geometry -- was not profiled.  want_issue: the entry itself (its SQ_INSTS_VALU / SQ_INSTS_SALU per launch feed
+    issue_roofline)."""
     for name in TRAFFIC_FILES:
         try:
             doc = json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -299,8 +301,28 @@ def measured_traffic(kernel, frames, width, rows, mode):
         for e in doc.get("entries", []):
             if (e["kernel"] == kernel and e["frames"] == frames and e["width"] == width
                     and e["rows"] == rows and e["mode"] == mode and e.get("traffic_bytes")):
-                return e["traffic_bytes"], "profiles/%s (separate rocprofv3 --pmc passes of this workload)" % name
+                src = "profiles/%s (separate rocprofv3 --pmc passes of this workload)" % name
+                if want_issue:
+                    return e, src
+                return e["traffic_bytes"], src
     return None, None
+
+
+def issue_roofline(kernel, frames, width, rows, mode, kernel_ms):
+    """Issue-rate roofline of the dominant kernel: vector + scalar wave-instructions per launch from the
+    committed PMC pass (SQ_INSTS_VALU, SQ_INSTS_SALU) / the kernel's live-measured duration, against one wave64 VALU
+    instruction per SIMD every 2 cycles at 2.4 GHz.  'valu_frac' is what the HBM roofline cannot say about a kernel that
+    moves few bytes per instruction: how close the SIMDs are to issuing a vector instruction whenever they could.  None
+    when the workload's instruction counts are not on record."""
+    e, src = measured_traffic(kernel, frames, width, rows, mode, want_issue=True)
+    if not e or not e.get("insts_valu"):
+        return None
+    valu, salu = float(e["insts_valu"]), float(e.get("insts_salu") or 0.0)
+    rate = valu / (kernel_ms * 1e-3)
+    return {"bound": "valu_issue", "achieved": round(rate / 1e9, 2), "peak": round(VALU_ISSUE_PEAK / 1e9, 2),
+            "unit": "G wave-instructions/s", "valu_frac": round(rate / VALU_ISSUE_PEAK, 4),
+            "insts_valu_per_launch": valu, "insts_salu_per_launch": salu,
+            "cycles_per_valu_instruction_and_simd": round(VALU_ISSUE_PEAK * 2.0 / rate, 3), "source": src}
 
 
 def self_launch(args):
@@ -580,7 +602,8 @@ def main():
                          "timed_passes_averaged": timed,
                          "pass_ms": round(pass_ms, 4),
                          "pass_frac": round(alg_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "pixels_redone_by_exact_kernel": st.last_fallback_pixels},
+                         "pixels_redone_by_exact_kernel": st.last_fallback_pixels,
+                         "issue": issue_roofline(st.last_kernel_name, n, w, rows, args.mode, k_ms)},
             # ms_per_step times passes queued back to back (one host sync at the end of the timed region);
             # this is one pass run the way OpStack.Apply runs it: enqueue, wait, read the counters back
             "ms_per_step_synchronous": round(tm["sync_ms"], 4),
@@ -658,6 +681,7 @@ def main():
                      "algorithmic_bytes": alg, "clip_low": t2["cl"], "clip_high": t2["ch"],
                      "pixels_redone_by_exact_kernel": st2.last_fallback_pixels}
                 e["traffic"], e["traffic_source"] = measured_traffic(st2.last_kernel_name, frames, gw, grows, mode)
+                e["roofline_issue"] = issue_roofline(st2.last_kernel_name, frames, gw, grows, mode, t2["k_ms"])
                 if t2["ranks"] is not None:
                     e["ranks"] = t2["ranks"]
                 if mode == 5:
@@ -672,6 +696,15 @@ def main():
                     e["goal_seek"] = {"target_percent": [0.5, 0.5], "passes": gpasses, "sigma_low": gsl, "sigma_high": gsh,
                                       "clip_low": gcl, "clip_high": gch,
                                       "total_ms": round((time.perf_counter() - t0) * 1e3, 3)}
+                    # the same bisection step by step: what each step's pass costs inside the sequence and what a pass at the
+                    # SAME sigmas costs in steady state (round 6: the two agree -- a goal-seek step carries no overhead of its
+                    # own; the total differs from passes x the kappa-3 pass because the steps are not kappa-3 passes: the
+                    # third one clips 5 % of the samples)
+                    from tools.goalseek_probe import step_table
+                    gsteps, _ = step_table(st2, mode)
+                    e["goal_seek"]["steps"] = gsteps
+                    e["goal_seek"]["sum_pass_ms_in_sequence"] = round(sum(x["pass_ms"] for x in gsteps), 3)
+                    e["goal_seek"]["sum_steady_pass_ms_at_the_same_sigmas"] = round(sum(x["steady_pass_ms"] for x in gsteps), 3)
                 if world == 1 and not args.no_cpu:
                     # parity flag: the first rows of the tile through the C ABI against the oracle (one run, all host threads)
                     prow = min(16, grows)

@@ -64,7 +64,9 @@ typedef struct nl_stack nl_stack_t;
 const char *nl_last_error(void);
 /* number of visible HIP devices, or a negative error */
 int nl_device_count(void);
-/* library version string */
+/* library version string.  0.2.0 (round 5 / 6): the OWNED frame buffer is padded -- frame k starts at
+ * nl_stack_frames_device_ptr(h) + k * nl_stack_frame_stride(h) floats, NOT at k * rows * width; a producer written
+ * against 0.1.0's dense layout must read the stride (or lend its own dense buffer with nl_stack_attach_device_frames). */
 const char *nl_version(void);
 /* nl_stack_destroy parks the large device buffers of a handle (frames, result, hand-over lists, the scratch of the
  * winsorized / linear-fit cascades and of weighted passes; per device at most 64 blocks and NL_MEM_CACHE_MB MiB -- default:
@@ -74,8 +76,12 @@ const char *nl_version(void);
  * HIP.  The library does so itself whenever ANY of its own device allocations fails (every one of them goes through
  * one helper that releases the cache and retries); allocations of OTHER code in the process (torch, RCCL) do not see
  * the parked blocks as free memory -- call this, or set NL_MEM_CACHE_MB=0, when the process shares the device.
- * The streams of destroyed handles are parked the same way (up to 32 idle streams per device: destroying a handle's two or
- * three streams was 0.5 ms of its 0.55 ms, creating them 0.2 of 0.24) and destroyed here as well.
+ * The streams of destroyed handles are parked the same way (main + side stream as the pair they were created as, copy
+ * streams in a list of their own, up to 16 of each per device: destroying a handle's two or three streams was 0.5 ms of
+ * its 0.55 ms, creating them 0.2 of 0.24; NL_STREAM_POOL=0 turns it off), and so are the pinned staging buffers of the
+ * asynchronous uploads (at most 16 blocks / 2 GiB per process: hipHostMalloc + hipHostFree of the ring were 20 ms of an
+ * Apply from host memory); all are released here as well.  The limits are per device (a sixteenth of THAT device's
+ * memory); a buffer above the limit -- the 32 GiB frame buffer of a 512 x 4096 x 4096 stack -- is never parked.
  * No counterpart in the reference. */
 void nl_release_cached_memory(void);
 
@@ -254,7 +260,10 @@ int nl_stack_set_exact(nl_stack_t *h, int on);
  * rounds run in one wave while the others sort the next block; also NL_MLZ_PERSIST=1) -- slower as well, same section.
  * bit 13 (8192) = generic pass and first replay of a short-listed sigma pass on two streams (the protocol of rounds 2 - 4)
  * instead of one launch (stack_tail_fused.hip; also NL_TAIL_FUSED=0), for A/B runs.
- * Default 0.  No counterpart in the reference. */
+ * Default 0.  Bits 10 and 11 (and nl_stack_set_exact(h, 4), and the environment switches NL_CHUNKS, NL_MLZ_SPLIT, NL_MLZ_PERSIST,
+ * NL_COOP4, NL_LFG) select code of the EXPERIMENTS build (make EXPERIMENTS=1 -> libnlstack_exp.so): the default library
+ * rejects the two bits and the flavour with NL_ERR_INVALID_ARG instead of running its one kernel under another name.
+ * No counterpart in the reference. */
 int nl_stack_set_dev_flags(nl_stack_t *h, unsigned flags);
 /* Pixels of the last pass that were re-done by the exact kernel. */
 int64_t nl_stack_last_fallback_pixels(nl_stack_t *h);
@@ -267,8 +276,9 @@ int64_t nl_stack_last_generic_pixels(nl_stack_t *h);
  * build).  No counterpart in the reference. */
 int nl_stack_last_pass_protocol(nl_stack_t *h);
 /* Linear-fit cascade of the last pass (stack_linfit.hip; StackLinearFit stack.go:834-918 has no
- * counterpart, diagnostics only): counts[s] = pixels stage s handed to stage s+1 (4 stages).
- * Writes min(n, 4) values; returns how many, 0 when the last pass ran no cascade. */
+ * counterpart, diagnostics only): counts[s] = pixels stage s handed to stage s+1 (4 stages; entries 4 ... 7 belong to the
+ * guarded stages of the experiments build and are zero in the default library).  Writes min(n, 8) values -- pass a buffer
+ * of 8 -- and returns how many, 0 when the last pass ran no cascade. */
 int nl_stack_linfit_stage_counts(nl_stack_t *h, unsigned *counts, int n);
 /* Name of the dominant kernel launched by the last pass (for profiles). */
 const char *nl_stack_last_kernel_name(nl_stack_t *h);

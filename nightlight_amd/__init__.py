@@ -11,4 +11,4 @@ from .capi import (NlError, ST_AUTO, ST_LINEAR_FIT, ST_MAD_SIGMA, ST_MEAN, ST_ME
 from .stack import (StackGroup, StackHandle, fits_padded_bytes, fits_parse_header, fits_write_header,  # noqa: F401
                     median_filter_3x3, median_filter_mask, weights_from_scalars)
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

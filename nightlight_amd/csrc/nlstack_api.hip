@@ -95,18 +95,28 @@ size_t g_cache_bytes = 0;
 // Limit of the parked bytes: NL_MEM_CACHE_MB if set (0 = off), else a sixteenth of the device's memory (18 GB of an
 // MI355X's 288: the frame buffer of the headline stack is 8 GiB) -- blocks parked by this library are invisible to the
 // other allocators of the process (torch, RCCL) until an allocation of OURS fails, so the default stays small.
-size_t cache_limit()
+size_t cache_limit(int device = -1)
 {
-    static const size_t lim = [] {
-        if (const char *e = getenv("NL_MEM_CACHE_MB")) {
-            const long long mb = atoll(e);
-            return mb > 0 ? (size_t)mb << 20 : (size_t)0;
-        }
+    static const long long env_mb = [] { const char *e = getenv("NL_MEM_CACHE_MB"); return e ? atoll(e) : -1ll; }();
+    if (env_mb >= 0) return env_mb > 0 ? (size_t)env_mb << 20 : (size_t)0;
+    // a sixteenth of THAT device's memory (a table per device: the limit used to be whatever device was current at the
+    // first free, applied to all)
+    static std::mutex mu;
+    static std::vector<size_t> per_device;
+    std::lock_guard<std::mutex> lk(mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (device < 0) device = cur;
+    if ((size_t)device >= per_device.size()) per_device.resize((size_t)device + 1, 0);
+    if (per_device[(size_t)device] == 0) {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return (size_t)4096 << 20; }
-        return total_b / 16;
-    }();
-    return lim;
+        if (device != cur) (void)hipSetDevice(device);
+        const bool ok = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        if (device != cur) (void)hipSetDevice(cur);
+        per_device[(size_t)device] = ok ? total_b / 16 : (size_t)4096 << 20;
+    }
+    return per_device[(size_t)device];
 }
 
 void cache_release_all()
@@ -166,7 +176,7 @@ void cached_free(void *p, size_t bytes, int device)
         for (const CachedBlock &b : g_cache)
             if (b.device == device) { blocks++; parked += b.bytes; }
         static const int max_blocks = [] { const char *e = getenv("NL_CACHE_BLOCKS"); return e ? atoi(e) : kCacheBlocks; }();
-        if (blocks < max_blocks && parked + bytes <= cache_limit()) {
+        if (blocks < max_blocks && parked + bytes <= cache_limit(device)) {
             g_cache.push_back({device, bytes, p});
             g_cache_bytes += bytes;
             return;
@@ -544,9 +554,9 @@ const char *nl_last_error(void) { return g_err.c_str(); }
 const char *nl_version(void)
 {
 #ifdef NL_EXPERIMENTS
-    return "nlstack 0.1.0 (gfx950) +experiments";
+    return "nlstack 0.2.0 (gfx950) +experiments";
 #else
-    return "nlstack 0.1.0 (gfx950)";
+    return "nlstack 0.2.0 (gfx950)";
 #endif
 }
 
@@ -1859,6 +1869,13 @@ float nl_stack_last_dominant_kernel_ms(nl_stack_t *h)
 int nl_stack_set_exact(nl_stack_t *h, int on)
 {
     NL_CHECK_HANDLE(h);
+    if (on < 0 || on > 4) return fail(NL_ERR_INVALID_ARG, "set_exact: unknown flavour %d (0 ... 4)", on);
+#ifndef NL_EXPERIMENTS
+    // (a switch this build does not carry must not fall through to another kernel silently: an A/B run would time the same
+    // kernel twice)
+    if (on == 4)
+        return fail(NL_ERR_INVALID_ARG, "set_exact: flavour 4 (four pixels per wave) is in the experiments build only (make EXPERIMENTS=1)");
+#endif
     h->force_exact = on != 0;
     h->exact_flavour = on;
     return NL_OK;
@@ -1867,6 +1884,11 @@ int nl_stack_set_exact(nl_stack_t *h, int on)
 int nl_stack_set_dev_flags(nl_stack_t *h, unsigned flags)
 {
     NL_CHECK_HANDLE(h);
+#ifndef NL_EXPERIMENTS
+    if (flags & (1024u | 2048u))
+        return fail(NL_ERR_INVALID_ARG, "set_dev_flags: switches 1024 / 2048 (split / persistent LDS-column pass) are in the experiments "
+                                        "build only (make EXPERIMENTS=1)");
+#endif
     h->dev_flags = flags;
     return NL_OK;
 }

@@ -24,6 +24,29 @@ namespace nl {
 #ifndef NL_LF_CHUNK
 #define NL_LF_CHUNK 8
 #endif
+// Parked chunks (round 6, NS = 128 only).  At three waves per SIMD the kernel has 168 registers, 128 of them the column: the
+// allocator spilled 9 - 31 of the rest to scratch and re-loaded ~20 of them per fit iteration -- SQ_WAIT_ANY (waves parked at
+// s_waitcnt) was 25 % of the wave cycles of the first stage (profiles/r06_linfit_pmc.txt), and three waves do not hide it.  The
+// NL_LF_PARK lowest and NL_LF_PARK highest chunks of the sorted column therefore live in LDS instead ([slot][thread]:
+// ds_read2st64_b32 with constant offsets, conflict-free) and are read back chunk by chunk inside the sweeps.  The ends are the
+// chunks that die first (the reference rejects from the ends inwards; pads sit on top), so their reads fade out with the
+// iterations.  Measured on 128 / 112 / 100 frames x 4096^2 (profiles/r06_linfit_park.txt): nothing parked 16.8 / 14.8 / 13.5 ms,
+// one chunk per end 16.0 / 13.9 / 12.7, two 16.2 / 14.0 / 12.8, three 16.8 / 14.3 / 12.9; every fourth chunk with its reads issued
+// one chunk ahead 16.1 - 16.4 / 14.1 (the reads ahead cost the registers the parking freed).  A fourth wave is out of reach: 128
+// registers would leave ~70 for the column, i.e. 58 parked samples = 14.5 KiB per wave, and 16 waves x 14.5 KiB exceed the
+// CU's 160 KiB.  NL_LF_PARK=0: everything in registers (the kernel of rounds 2 - 5).
+#ifndef NL_LF_PARK
+#define NL_LF_PARK 1
+#endif
+template <int NS, int CH>
+struct LfPark {
+    static constexpr int NC = NS / CH;
+    static constexpr int ends = (NS == 128) ? NL_LF_PARK : 0;
+    static constexpr int slots = 2 * ends * CH;                       // parked samples per pixel
+    static constexpr __host__ __device__ bool parked(int c) { return c < ends || c >= NC - ends; }
+    static constexpr __host__ __device__ int slot(int c) { return c < ends ? c : c - (NC - 2 * ends); }
+};
+
 template <int NS, bool CONT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS > 96 ? 3 : 1, 8)))
 void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
@@ -80,6 +103,27 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
     }
     const bool to_exact = inf_any != 0;
 
+    using Park = LfPark<NS, NL_LF_CHUNK>;
+    __shared__ float park[Park::slots > 0 ? Park::slots : 1][256];
+    if constexpr (Park::slots > 0) {
+        static_range<0, NS / NL_LF_CHUNK>([&](auto C) NL_INL {
+            constexpr int c = decltype(C)::value;
+            if constexpr (Park::parked(c))
+                static_range<0, NL_LF_CHUNK>([&](auto J) NL_INL {
+                    constexpr int j = decltype(J)::value;
+                    park[Park::slot(c) * NL_LF_CHUNK + j][threadIdx.x] = v[c * NL_LF_CHUNK + j];
+                });
+        });
+    }
+    // x[0..CH) = the samples of chunk c: registers, or (parked chunks) this thread's column slots in LDS
+#define NL_CHUNK_VALS(c, x)                                                                                  \
+    float x[NL_LF_CHUNK];                                                                                    \
+    static_range<0, NL_LF_CHUNK>([&](auto J_) NL_INL {                                                        \
+        constexpr int j_ = decltype(J_)::value;                                                              \
+        if constexpr (Park::slots > 0 && Park::parked(c)) x[j_] = park[Park::slot(c) * NL_LF_CHUNK + j_][threadIdx.x]; \
+        else x[j_] = v[(c) * NL_LF_CHUNK + j_];                                                              \
+    })
+
     float res = p.ref_loc;
     int p_lo = 0, p_hi = 0;
     int m = m_saved;                            // surviving samples
@@ -125,12 +169,14 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
             if ((ad >> c) & 1u) {
             } else if ((aa >> c) & 1u) {
                 NL_KEEP_BRANCH;
-                static_range<c * CH, c * CH + CH>([&](auto K) NL_INL { s = __fadd_rn(s, v[decltype(K)::value]); });
+                NL_CHUNK_VALS(c, x);
+                static_range<0, CH>([&](auto J) NL_INL { s = __fadd_rn(s, x[decltype(J)::value]); });
             } else {
                 NL_KEEP_BRANCH;
+                NL_CHUNK_VALS(c, x);
                 static_range<c * CH, c * CH + CH>([&](auto K) NL_INL {
                     constexpr int k = decltype(K)::value;
-                    s = __fadd_rn(s, NL_AND(v[k], NL_M(k)));
+                    s = __fadd_rn(s, NL_AND(x[k - c * CH], NL_M(k)));
                 });
             }
         });
@@ -147,19 +193,21 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
                 NL_KEEP_BRANCH;
                 // fl(i - xm) is exact (half-integers below 2^23), so (fi - xm) + j is the same float
                 const float dxb = __fsub_rn(fi, xm);
+                NL_CHUNK_VALS(c, x);
                 static_range<0, CH>([&](auto J) NL_INL {
                     constexpr int j = decltype(J)::value;
-                    const float dy = __fsub_rn(v[c * CH + j], ym);
+                    const float dy = __fsub_rn(x[j], ym);
                     vs = __fadd_rn(vs, __fmul_rn(dy, dy));
                     corr = __fadd_rn(corr, __fmul_rn(__fadd_rn(dxb, (float)j), dy));
                 });
                 fi += (float)CH;
             } else {
                 NL_KEEP_BRANCH;
+                NL_CHUNK_VALS(c, x);
                 static_range<c * CH, c * CH + CH>([&](auto K) NL_INL {
                     constexpr int k = decltype(K)::value;
                     const int lm = NL_M(k);
-                    const float dy = __fsub_rn(v[k], ym);
+                    const float dy = __fsub_rn(x[k - c * CH], ym);
                     const float dd = __fmul_rn(dy, dy);
                     vs = __fadd_rn(vs, NL_AND(dd, lm));
                     const float dx = __fsub_rn(fi, xm);
@@ -184,7 +232,10 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
         // residuals each: the compiler re-associates fmaxf / fminf chains into a tree over all
         // the residuals and spills the column for it.
         float sg = 0.0f;
-        float dmax[NW], dmin[NW];               // per 32 positions
+        // (per 32 positions.  Per chunk, for the shallow columns whose iterations are issue-bound: 25 / 32 / 48 / 64 frames
+        // 2.35 / 2.68 / 4.30 / 6.03 -> 2.42 / 2.70 / 4.25 / 6.04 ms, round 6 -- the masked reject pass over chunks without a
+        // candidate is not where a shallow iteration's time goes)
+        float dmax[NW], dmin[NW];
         static_range<0, NW>([&](auto W) NL_INL { dmax[decltype(W)::value] = -__builtin_inff(); dmin[decltype(W)::value] = __builtin_inff(); });
         fi = 0.0f;
         forget_words<NW>(live);
@@ -194,10 +245,11 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
             } else if ((aa >> c) & 1u) {
                 NL_KEEP_BRANCH;
                 float dprev = 0.0f;
+                NL_CHUNK_VALS(c, x);
                 static_range<0, CH>([&](auto J) NL_INL {
                     constexpr int j = decltype(J)::value;
                     const float lin = __fadd_rn(__fmul_rn(__fadd_rn(fi, (float)j), slope), icpt);
-                    const float diff = __fsub_rn(v[c * CH + j], lin);
+                    const float diff = __fsub_rn(x[j], lin);
                     sg = __fadd_rn(sg, fabsf(diff));
                     if constexpr ((j & 1) == 0) {
                         dprev = diff;
@@ -209,11 +261,12 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
                 fi += (float)CH;
             } else {
                 NL_KEEP_BRANCH;
+                NL_CHUNK_VALS(c, x);
                 static_range<c * CH, c * CH + CH>([&](auto K) NL_INL {
                     constexpr int k = decltype(K)::value;
                     const int lm = NL_M(k);
                     const float lin = __fadd_rn(__fmul_rn(fi, slope), icpt);
-                    const float diff = __fsub_rn(v[k], lin);
+                    const float diff = __fsub_rn(x[k - c * CH], lin);
                     sg = __fadd_rn(sg, NL_AND(fabsf(diff), lm));
                     fi += NL_AND(1.0f, lm);
                 });
@@ -256,10 +309,11 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
                 // fl(g - lin) == -fl(lin - g)), shifted into one word per test with v_alignbit;
                 // liveness, counts and the mask update once per chunk
                 unsigned lowb = 0, highb = 0;
+                NL_CHUNK_VALS(c, x);
                 static_range<0, CH>([&](auto J) NL_INL {
                     constexpr int k = c * CH + decltype(J)::value;
                     const float lin = __fadd_rn(__fmul_rn(fi, slope), icpt);
-                    const float t = __fsub_rn(lin, v[k]);
+                    const float t = __fsub_rn(lin, x[k - c * CH]);
                     lowb = __builtin_amdgcn_alignbit(lowb, (unsigned)__float_as_int(__fsub_rn(lb, t)), 31);
                     highb = __builtin_amdgcn_alignbit(highb, (unsigned)__float_as_int(__fadd_rn(hb, t)), 31);
                     fi += NL_AND(1.0f, NL_M(k));
@@ -286,6 +340,8 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
             static_range<0, NW>([&](auto W) NL_INL { live[decltype(W)::value] = nlive[decltype(W)::value]; });
         }
     }
+
+#undef NL_CHUNK_VALS
 
     // lanes that are still fitting after this stage's quota go to the next stage; the
     // rejections they made so far are final and are counted here
@@ -654,20 +710,30 @@ int linfit_ml_supported(int mode, int n_frames, int64_t npix)
     return (mode == NL_ST_LINEAR_FIT && n_frames > 128 && n_frames <= 512 && npix < ((int64_t)1 << 27)) ? 1 : 0;
 }
 
-// fit iterations per cascade stage (the last stage runs to the end); NL_LF_QUOTA="a,b,c" overrides
-// the first three for tuning runs
-static const int *linfit_quota()
+// fit iterations per cascade stage (the last stage runs to the end); NL_LF_QUOTA="a,b,c" overrides.
+// 8 / 6 / 8 measured best on 128 x 4096^2 in round 2 (19.7 ms vs 20.2 (6,6,8), 20.4 (10,8,8), 21.1 (5,5,8)) and again in round 6
+// (flat within 1 % between 8,6,8 / 6,6,8 / 6,4,6), and best up to 40 frames (32 frames: 2.68 ms, 6,6,8: 3.50 -- a shallow
+// continuation stage is a poor trade).  In between the first stage wants to stop earlier (round 6, profiles/r06_linfit_quota.txt):
+// 48 frames 4.31 -> 3.98 ms with 7,6,8; 56 / 64 / 72 / 80 frames 5.46 / 6.07 / 8.32 / 9.13 -> 4.90 / 5.71 / 8.03 / 8.99 with 6,6,8;
+// 96 frames 10.96 -> 10.84 with 7,6,8.
+static const int *linfit_quota(int n_frames)
 {
-    static int quota[kLinfitStages] = {8, 6, 8, 0};     // measured: 19.7 ms vs 20.2 (6,6,8), 20.4 (10,8,8), 21.1 (5,5,8) on 128 x 4096^2
-    static bool parsed = false;
-    if (!parsed) {
-        parsed = true;
+    static int env_quota[kLinfitStages] = {0, 0, 0, 0};
+    static const bool from_env = [] {
         if (const char *e = getenv("NL_LF_QUOTA")) {
             int a = 0, b = 0, c = 0;
-            if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { quota[0] = a; quota[1] = b; quota[2] = c; }
+            if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) {
+                env_quota[0] = a; env_quota[1] = b; env_quota[2] = c;
+                return true;
+            }
         }
-    }
-    return quota;
+        return false;
+    }();
+    if (from_env) return env_quota;
+    static const int q868[kLinfitStages] = {8, 6, 8, 0}, q768[kLinfitStages] = {7, 6, 8, 0}, q668[kLinfitStages] = {6, 6, 8, 0};
+    if (n_frames <= 40 || n_frames > 96) return q868;
+    if (n_frames <= 48 || n_frames > 80) return q768;
+    return q668;
 }
 
 template <int LPP>
@@ -682,7 +748,7 @@ static void launch_lf_ml(const StackArgs &args, const FastArgs &f, const LinfitC
         if (dominant_done) (void)hipEventRecord(dominant_done, stream);
         return;
     }
-    const int *quota = linfit_quota();                          // as the one-lane kernel
+    const int *quota = linfit_quota(args.n_frames);             // as the one-lane kernel
     for (int s = 0; s < kLinfitStages; s++) {
         g.max_iters = quota[s];
         g.in_list = s ? c->list[(s - 1) & 1] : nullptr;
@@ -735,7 +801,7 @@ static void launch_lf(const StackArgs &args, const FastArgs &f, const LinfitCasc
     // Fit iterations per stage.  The number a pixel needs varies a lot (8 on average, 20-26
     // for the slowest lane of a wave): capping a stage and re-packing the unfinished pixels
     // into full waves halves the lane-iterations, at the price of re-sorting those pixels.
-    const int *quota = linfit_quota();
+    const int *quota = linfit_quota(args.n_frames);
     for (int s = 0; s < kLinfitStages; s++) {
         g.max_iters = quota[s];
         g.in_list = s ? c->list[(s - 1) & 1] : nullptr;

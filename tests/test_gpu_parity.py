@@ -992,3 +992,103 @@ def test_generic_pass_and_first_replay_in_one_launch(nl, oracle, n, nan_frac):
             out, cl, ch = st.run(2, *kappas[1])
             seen.add((cl, ch, out.tobytes()))
         assert len(seen) == 1
+
+
+# ---- round 6 ------------------------------------------------------------------------------------------------------------
+def test_owned_frame_buffer_is_padded_and_the_stride_is_what_producers_must_use(nl):
+    # nlstack 0.2.0: frame k of the OWNED buffer starts at frames_device_ptr + k * frame_stride floats, and for the headline
+    # geometry (and every tile of 256 Ki pixels or more) that stride is NOT rows * width.  A producer
+    # written against the dense layout of 0.1.0 would corrupt the stack silently: this pins the contract.
+    import ctypes
+    from nightlight_amd import capi
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    lib.nl_version.restype = ctypes.c_char_p
+    assert b"0.2." in lib.nl_version()
+    with nl.StackHandle(4, 4096, 4096) as st:                       # the headline's tile (4 frames: 256 MiB)
+        npix = 4096 * 4096
+        assert st.frame_stride() > npix and st.frame_stride() % 64 == 0, st.frame_stride()
+        st.fill_synthetic(3)
+        a = st.download_tile(1)
+        # the same frame through the raw pointer and the stride (what an in-place producer addresses): a second handle that
+        # borrows the buffer with that stride reads the same bits; borrowed as a DENSE buffer it reads frame 1 from elsewhere
+        with nl.StackHandle(4, 4096, 4096) as b:
+            b.attach_device_frames(st.frames_device_ptr(), st.frame_stride())
+            assert bits_equal(b.download_tile(1), a)
+            b.attach_device_frames(st.frames_device_ptr())
+            assert not bits_equal(b.download_tile(1), a)
+            b.attach_device_frames(None)
+    with nl.StackHandle(4, 256, 64) as st:                          # small tiles stay dense
+        assert st.frame_stride() == 256 * 64
+
+
+def test_switches_of_the_experiments_build_are_rejected_by_the_default_library(nl):
+    # nl_stack_set_exact(h, 4) and developer switches 1024 / 2048 select kernels only libnlstack_exp.so carries: the default
+    # library must say so instead of timing its one kernel under another name
+    import ctypes
+    from nightlight_amd import capi
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    lib.nl_version.restype = ctypes.c_char_p
+    exp = b"+experiments" in lib.nl_version()
+    with nl.StackHandle(8, 64, 8) as st:
+        for call, arg in ((st.set_exact, 4), (st.set_dev_flags, 1024), (st.set_dev_flags, 2048 | 1)):
+            if exp:
+                call(arg)
+            else:
+                with pytest.raises(capi.NlError) as e:
+                    call(arg)
+                assert "experiments build" in str(e.value)
+        with pytest.raises(capi.NlError):
+            st.set_exact(5)
+        st.set_exact(0)
+        st.set_dev_flags(0)
+
+
+def _adversarial_winsor_columns(n, pixels, seed):
+    """Columns that sit on the edges of the invariant-interval certificate (stack_fast_sigma_impl.hpp, CERT): ties exactly
+    at the clamp, all-equal columns, two-valued columns ({x, y, y}: > 60 winsorization rounds in the reference), one far
+    outlier, a standard deviation that RISES in round 1, half the column NaN, and plain noise in between."""
+    rng = np.random.default_rng(seed)
+    f = (1000.0 + 30.0 * rng.standard_normal((n, pixels))).astype(np.float32)
+    k = np.arange(pixels)
+    kind = k % 8
+    for p in np.flatnonzero(kind == 1):                      # all equal
+        f[:, p] = np.float32(1000.0 + (p % 5))
+    for p in np.flatnonzero(kind == 2):                      # {x, y, y, ...}
+        f[:, p] = np.float32(1200.0)
+        f[p % n, p] = np.float32(1000.0)
+    for p in np.flatnonzero(kind == 3):                      # ties at median -+ 1.5 sigma of the first round
+        col = np.float32(1000.0) + np.float32(8.0) * np.round(rng.standard_normal(n) * 2.0).astype(np.float32)
+        f[:, p] = col
+    for p in np.flatnonzero(kind == 4):                      # one far outlier: sigma collapses after the first clamp
+        f[(p // 8) % n, p] = np.float32(60000.0)
+    for p in np.flatnonzero(kind == 5):                      # two clusters: the clamped deviation rises, then falls
+        f[: n // 2, p] = np.float32(900.0) + np.float32(0.5) * rng.standard_normal(n // 2).astype(np.float32)
+        f[n // 2:, p] = np.float32(1100.0) + np.float32(0.5) * rng.standard_normal(n - n // 2).astype(np.float32)
+    for p in np.flatnonzero(kind == 6):                      # half the column missing
+        f[rng.permutation(n)[: n // 2], p] = np.nan
+    return f
+
+
+@pytest.mark.parametrize("n", [12, 13, 15, 16, 17, 20, 24, 25, 32, 40, 48, 64, 96, 100, 128])
+def test_winsor_certificate_on_and_off_give_identical_counters(nl, oracle, n):
+    # ADVICE r05: the certificate leaves the winsorization loop early on the strength of a monotonicity argument and ad hoc
+    # margins; the fuzz logs covered it, the suite did not.  Adversarial columns, certificate on (default) and off (developer
+    # switch 16384), negative and asymmetric sigmas included: same counters, values within 1e-5, and the oracle's counters.
+    width, height = 512, 6
+    frames = _adversarial_winsor_columns(n, width * height, seed=6000 + n)
+    for sl, sh in ((3.0, 3.0), (1.0, 2.5), (2.75, 0.5), (-1.0, 2.0)):
+        with nl.StackHandle(n, width, height) as st:
+            st.upload_frames(frames)
+            res = {}
+            for flags in (0, 16384, 0):
+                st.set_dev_flags(flags)
+                res.setdefault(flags, []).append(st.run(3, sl, sh))
+            (a, al, ah), (a2, al2, ah2) = res[0]
+            (b, bl, bh), = res[16384]
+            assert (al, ah) == (bl, bh) == (al2, ah2), "n=%d sigma %r: counters %r / %r / %r" % (n, (sl, sh), (al, ah), (bl, bh), (al2, ah2))
+            # (values: a pixel that leaves the loop early is finished by the register kernel, one that runs into the round
+            # cap without the certificate by the bit-exact replay -- two summation orders, so 1e-5 and not bits)
+            assert close_values(a, b) and close_values(a, a2), "n=%d sigma %r: %s" % (n, (sl, sh), describe_mismatch(a, b))
+        rc, want, wl, wh, _ = oracle.stack_apply(3, frames, None, sl, sh, 0.0, num_cpu=4)
+        assert rc == 0 and (al, ah) == (wl, wh), "n=%d sigma %r: counters %r vs oracle %r" % (n, (sl, sh), (al, ah), (wl, wh))
+        assert close_values(a, want), "n=%d sigma %r: %s" % (n, (sl, sh), describe_mismatch(a, want))

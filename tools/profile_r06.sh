@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 profile set (run on the GPU box from the repo root), then tools/collect_profiles.py r05 <tags>.
+# Round-6 profile set (run on the GPU box from the repo root), then tools/collect_profiles.py r06 <tags>.
 set -u
 P=tools/gpu_profile.sh
 timeout 300 $P sigma128

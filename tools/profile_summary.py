@@ -50,7 +50,7 @@ def traffic(pmc_txt, bench_json):
             kernel = l.strip()
             continue
         f = l.split()
-        if kernel and base in kernel and f[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+        if kernel and base in kernel and f[0] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU"):
             v = float(f[2].split("=")[1])
             if v > best.get((f[0]), (0.0, ""))[0]:
                 best[f[0]] = (v, kernel)
@@ -60,6 +60,8 @@ def traffic(pmc_txt, bench_json):
              "fetch_size_kib": fetch, "write_size_kib": write,
              "traffic_bytes": 2.0 * fetch * 1024.0 + write * 1024.0,
              "algorithmic_bytes": roof["algorithmic_bytes"],
+             # wave-instructions per launch (issue-rate roofline of bench.py, round 6)
+             "insts_valu": best.get("SQ_INSTS_VALU", (0.0, ""))[0], "insts_salu": best.get("SQ_INSTS_SALU", (0.0, ""))[0],
              "profiled_kernel": best.get("FETCH_SIZE", (0.0, ""))[1]}
     return json.dumps(entry)
 

@@ -635,7 +635,8 @@ def main():
                     c = fresh_handle_cost(st, n, m_, wt_)
                     out["fresh_handle"][tag] = {k: c[k] for k in ("ms_create", "ms_first_pass_fresh_handle", "ms_destroy", "ms_create_destroy")}
 
-    if rank == 0 and world == 1 and dist is None and default_workload_early and (args.apply or not (args.no_apply or args.no_cpu)):     # (--no-cpu skips both host-side legs)
+    if rank == 0 and world == 1 and dist is None and weights is None and (
+            args.apply or (default_workload_early and not (args.no_apply or args.no_cpu))):     # (--no-cpu skips both host-side legs; --apply: any geometry)
         want = st.download_rows(-1, 0, rows)          # result of the last resident pass (same frames, same kappa)
         out["apply_from_host"] = apply_from_host(st, n, w, image_rows, args.mode, args.kappa, device, want, (cl, ch))
     st.close()

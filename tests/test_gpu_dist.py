@@ -331,3 +331,20 @@ def test_bench_force_dist_reports_the_rccl_protocol_on_one_gpu():
     assert (one["config"]["clip_low"], one["config"]["clip_high"]) == (doc["config"]["clip_low"], doc["config"]["clip_high"])
     assert "fresh_handle" in one and one["fresh_handle"]["ms_first_pass_fresh_handle"] > 0
     assert one["fresh_handle"]["clip_counters"] == [one["config"]["clip_low"], one["config"]["clip_high"]]
+
+
+def test_bench_apply_from_host_leg_matches_the_resident_pass():
+    # bench.py apply_from_host (round 6): OpStack.Apply from pageable host frames through nl_group_create /
+    # nl_group_upload_frame[_fits] / nl_group_run / nl_group_destroy, as go/stackhip/stack_hip.go calls them -- here on a small
+    # stack (--apply runs the leg for any geometry): the fp32 leg must reproduce the resident pass's result and counters
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "12", "--width", "512", "--height", "96",
+           "--steps", "2", "--warmup", "1", "--preheat-steps", "1", "--no-cpu", "--no-also", "--apply"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    doc = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    a = doc["apply_from_host"]
+    assert a["fp32"]["result_equals_resident_pass"] and a["fp32"]["counters_equal_resident_pass"]
+    for leg in ("fp32", "fits_int16"):
+        assert a[leg]["wall_ms"] > 0 and a[leg]["upload_gib_s"] > 0
+        assert set(a[leg]["share"]) == {"upload", "pass", "download", "create_destroy"}
+    assert a["fits_int16"]["host_bytes"] * 2 == a["fp32"]["host_bytes"]

@@ -4,7 +4,7 @@
     python tools/check_bench.py bench.json            exit 1 if any workload's pass, step or tail is slower than the band allows
     python tools/check_bench.py --update bench.json   rewrite the expectations from this bench line (same commit as the library!)
 
-Per tag: ms_per_step and pass_ms may exceed the expectation by band_pct (5 %: the pool's boxes differ by up to that), the tail
+Per tag: ms_per_step and pass_ms may exceed the expectation by band_pct (8 %: the pool's boxes differ by up to 7 % on the HBM-bound workloads), the tail
 pass_ms - kernel_ms by tail_band_pct (10 %) or tail_band_abs_ms, whichever is larger; the C3 tile's goal-seek total by band_pct.
 Faster never fails (it is reported so that the expectations get updated).  Rule of the repo since round 6: no library commit
 after the last bench that passed this check -- tools/final_check.sh runs build, suite, bench and this script in that order.

@@ -7,6 +7,10 @@
 #   blk16   this tree, NL_CACHE_BLOCKS=16          (d720fce off; the per-device accounting of 2da1693 is the same on one GPU)
 #   nocache this tree, NL_MEM_CACHE_MB=0
 # Run on the GPU box from the repo root: tools/bisect_tail.sh [out-dir]
+# (build/pre/libnlstack_pre.so is built in the BUILD container first -- only nlstack_api.hip and nlstack_group.hip differ:
+#    for f in nlstack_api nlstack_group; do git show d9feae8:nightlight_amd/csrc/$f.hip > nightlight_amd/csrc/pre_$f.hip; done
+#    hipcc <Makefile FLAGS> -c pre_<f>.hip -o build/pre/<f>.o; link with the default build's other objects; the leg is skipped when the
+#    library is not there)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=${1:-gpurun_out/bisect}; mkdir -p $O
 run() {  # tag, env...
@@ -26,7 +30,7 @@ for l in open(sys.argv[1]):
 PY
 }
 for rep in 1 2; do
-  run pre_$rep NLSTACK_LIB=$GRAFT_REPO_ROOT/build/pre/libnlstack_pre.so
+  [ -f $GRAFT_REPO_ROOT/build/pre/libnlstack_pre.so ] && run pre_$rep NLSTACK_LIB=$GRAFT_REPO_ROOT/build/pre/libnlstack_pre.so
   run head_$rep X=1
   run nopool_$rep NL_STREAM_POOL=0
   run blk16_$rep NL_CACHE_BLOCKS=16

@@ -162,7 +162,7 @@ def cpu_baseline(st, args, rows, weights=None, frames_n=None, mode=None, width=N
         dt1, _, _, _ = run(1, one_rows)
         per_thread = n * one_rows * w / dt1 / 1e6
         sweep = [{"threads": 1, "msamples_per_s": round(per_thread, 1), "s": round(dt1, 3), "rows": one_rows}]
-        counts = sorted({max(1, usable // 2), usable, min(threads, 2 * usable), threads} - {1})
+        counts = sorted({max(1, usable // 2), usable, min(threads, 2 * usable), threads} - {1}) or [1]
         best = None
         res = cc = None
         for c in counts:

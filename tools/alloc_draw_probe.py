@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Does the pass time of the LIBRARY depend on where a handle's frame buffer landed?  (run on the GPU box, NL_MEM_CACHE_MB=0)
+"""Does the pass time of the LIBRARY depend on where a handle's frame buffer landed?  (run on the GPU box, NL_MEM_CACHE_MB=0;
+the draw-at-create experiment of DESIGN 12.8 used a library build with nl_stack_frame_buffer_draws, not kept)
 Eight handles of the headline geometry created in a row and kept alive (so that every one gets other memory); on each: mean,
 median and sigma-clip passes, dominant-kernel ms (HIP events, mean of 10 after 5 warm-ups).  A bimodal column = the allocation
 lottery of DESIGN 11.9 seen through the product kernels."""

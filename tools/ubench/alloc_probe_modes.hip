@@ -1,0 +1,134 @@
+// Developer microbenchmark (round 6): which cheap probe sees the slow / fast mode of an 8 GiB allocation?
+// Per allocation: B = 16-byte loads, 8 frames in flight, NO store, on the UNTOUCHED allocation; then memset; A = the reference
+// pattern of alloc_lottery.hip (one lane per pixel, 128 loads in flight, one store per pixel); C = B again (touched);
+// D = B's loads with a 16-byte store per lane.  GB/s each (min of 3 runs after one warm-up).
+//   hipcc --offload-arch=gfx950 -O3 alloc_probe_modes.hip -o alloc_probe_modes && ./alloc_probe_modes [allocations]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#pragma clang diagnostic ignored "-Wunused-value"
+#pragma clang diagnostic ignored "-Wunused-result"
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void stream128(const float *frames, float *out, long npix, long stride)
+{
+    const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= npix) return;
+    float v[128];
+#pragma unroll
+    for (int k = 0; k < 128; k++) v[k] = __builtin_nontemporal_load(frames + pix + (long)k * stride);
+    float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+    for (int k = 0; k < 128; k += 4) { s0 += v[k]; s1 += v[k + 1]; s2 += v[k + 2]; s3 += v[k + 3]; }
+    out[pix] = (s0 + s1) + (s2 + s3);
+}
+
+template <bool STORE>
+__global__ __launch_bounds__(256) void vec4x8(const float *frames, float *out, long npix4, long stride)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix4) return;
+    const f4 *base = reinterpret_cast<const f4 *>(frames) + i;
+    const long stride4 = stride >> 2;
+    f4 acc = {0, 0, 0, 0};
+    for (int k = 0; k < 128; k += 8) {
+        f4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = __builtin_nontemporal_load(base + (long)(k + j) * stride4);
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc += v[j];
+    }
+    if (STORE) reinterpret_cast<f4 *>(out)[i] = acc;
+    else if (acc.x == 1.2345678e-30f && acc.y == 8.7654321e-31f) out[0] = acc.x;
+}
+
+__global__ __launch_bounds__(256) void fill_noise(float *p, long n)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        unsigned long x = (unsigned long)i * 0x9E3779B97F4A7C15ul; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ul; x ^= x >> 32;
+        p[i] = 1000.0f + 30.0f * ((float)(x & 0xffff) / 65536.0f - 0.5f);
+    }
+}
+
+template <class F>
+static float rate(F launch, long npix, int bytes_per_px_out)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int i = 0; i < 4; i++) {
+        hipEventRecord(e0);
+        launch();
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (i > 0 && ms < best) best = ms;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return (float)((double)npix * (128 * 4 + bytes_per_px_out) / best / 1e6);
+}
+
+int main(int argc, char **argv)
+{
+    const long npix = 4096L * 4096L, stride = npix + 16448;
+    const size_t bytes = (size_t)stride * 128 * sizeof(float) + (8u << 20);
+    float *out;
+    hipMalloc(&out, npix * sizeof(float));
+    const int nalloc = argc > 1 ? atoi(argv[1]) : 12;
+    float *buf[32];
+    const unsigned g1 = (unsigned)((npix + 255) / 256), g4 = (unsigned)((npix / 4 + 255) / 256);
+    for (int i = 0; i < nalloc && i < 32; i++) {
+        if (hipMalloc(&buf[i], bytes) != hipSuccess) { printf("no memory at %d\n", i); return 1; }
+        const float *f = buf[i];
+        // first launch on untouched memory, single shot (what a create-time probe would see) and min of 3
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0); hipLaunchKernelGGL(vec4x8<false>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); hipEventRecord(e1); hipEventSynchronize(e1);
+        float first = 0; hipEventElapsedTime(&first, e0, e1);
+        const float b = rate([&] { hipLaunchKernelGGL(vec4x8<false>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 0);
+        const float d0 = rate([&] { hipLaunchKernelGGL(vec4x8<true>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 4);
+        printf("allocation %2d: D on the UNTOUCHED allocation %7.1f GB/s\n", i, d0);
+        hipMemset(buf[i], 0, bytes);
+        hipDeviceSynchronize();
+        const float a = rate([&] { hipLaunchKernelGGL(stream128, dim3(g1), dim3(256), 0, 0, f, out, npix, stride); }, npix, 4);
+        const float c = rate([&] { hipLaunchKernelGGL(vec4x8<false>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 0);
+        const float d = rate([&] { hipLaunchKernelGGL(vec4x8<true>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 4);
+        printf("allocation %2d at %p: A ref %7.1f | B untouched, no store %7.1f (first shot %.3f ms) | C touched, no store %7.1f | D touched, store %7.1f GB/s\n",
+               i, (void *)buf[i], a, b, first, c, d);
+        fflush(stdout);
+    }
+    // does the mode belong to the FRAMES allocation alone, or to the pair (frames, out)?  D with six other out buffers and with
+    // the first out buffer's slack at offsets of 4 KiB ... 32 MiB
+    float *outs[6];
+    for (int j = 0; j < 6; j++) { hipMalloc(&outs[j], npix * sizeof(float) + (64u << 20)); hipMemset(outs[j], 0, npix * sizeof(float)); }
+    hipDeviceSynchronize();
+    for (int i = 0; i < nalloc && i < 32; i++) {
+        const float *f = buf[i];
+        printf("frames %2d: D with out buffers", i);
+        for (int j = 0; j < 6; j++) {
+            float *o = outs[j];
+            printf(" %6.0f", rate([&] { hipLaunchKernelGGL(vec4x8<true>, dim3(g4), dim3(256), 0, 0, f, o, npix / 4, stride); }, npix, 4));
+        }
+        printf(" | offsets into out buffer 0 (4K 64K 1M 8M 32M):");
+        const size_t offs[5] = {4u << 10, 64u << 10, 1u << 20, 8u << 20, 32u << 20};
+        for (int j = 0; j < 5; j++) {
+            float *o = outs[0] + offs[j] / 4;
+            printf(" %6.0f", rate([&] { hipLaunchKernelGGL(vec4x8<true>, dim3(g4), dim3(256), 0, 0, f, o, npix / 4, stride); }, npix, 4));
+        }
+        printf("\n");
+        fflush(stdout);
+    }
+    for (int i = 0; i < nalloc && i < 32; i++) {
+        hipLaunchKernelGGL(fill_noise, dim3(4096), dim3(256), 0, 0, buf[i], (long)(bytes / 4));
+        hipDeviceSynchronize();
+    }
+    for (int i = 0; i < nalloc && i < 32; i++) {
+        const float *f = buf[i];
+        const float d = rate([&] { hipLaunchKernelGGL(vec4x8<true>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 4);
+        const float a = rate([&] { hipLaunchKernelGGL(stream128, dim3(g1), dim3(256), 0, 0, f, out, npix, stride); }, npix, 4);
+        printf("noise-filled %2d: D store %7.1f | A ref %7.1f GB/s\n", i, d, a);
+    }
+    return 0;
+}

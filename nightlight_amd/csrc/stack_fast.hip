@@ -89,9 +89,13 @@ __global__ __launch_bounds__(256) void stack_median_fast_kernel(StackArgs p, Fas
             const __amdgpu_buffer_rsrc_t ors =
                 __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(p.npix * 4), 0x00020000);     // npix < 2^29 (dispatch)
             const unsigned so = (on && !hand_over) ? (unsigned)pix * 4u : 0xFFFFFFFFu;
+#ifdef NL_PLAIN_STORES
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(res), ors, (int)so, 0, 0);
+#else
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(res), ors, (int)so, 0, 2);     // aux 2 = nt, see NL_STORE_RESULT
+#endif
         } else {
-            if (on) p.out[pix] = res;
+            if (on) NL_STORE_RESULT(&p.out[pix], res);
         }
         if constexpr (WINDOW) {
             const unsigned long long gm = __ballot(hand_over);
@@ -214,7 +218,7 @@ void stack_mad_fast_kernel(StackArgs p, FastArgs q)
     float res = sum / f_kept;                                // no survivor: 0/0 = NaN, as the reference
     if (n == 0) res = p.ref_loc;
     const bool to_exact = on && degenerate;
-    if (on && !to_exact) p.out[pix] = res;
+    if (on && !to_exact) NL_STORE_RESULT(&p.out[pix], res);
     if (!on || to_exact || n == 0) { c_lo = 0; c_hi = 0; }
     c_lo_sum += c_lo;
     c_hi_sum += c_hi;
@@ -325,7 +329,7 @@ void stack_mad_bitonic_kernel(StackArgs p, FastArgs q)
     float res = sum / f_kept;                                // no survivor: 0/0 = NaN, as the reference
     if (n == 0) res = p.ref_loc;
     const bool to_exact = on && degenerate && !narrow;
-    if (on && !to_exact && !narrow) p.out[pix] = res;
+    if (on && !to_exact && !narrow) NL_STORE_RESULT(&p.out[pix], res);
     if (!on || to_exact || narrow || n == 0) { c_lo = 0; c_hi = 0; }
     const unsigned long long em = __ballot(to_exact), gm = __ballot(narrow);
     if (em) {

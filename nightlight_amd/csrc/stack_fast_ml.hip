@@ -455,7 +455,7 @@ void stack_median_ml_kernel(StackArgs p)
     const float lower = pick_rank<LPP, NS, NS, NS>(v, kk > 0 ? kk - 1 : 0, role, 0);
     float res = (n & 1) ? upper : 0.5f * (lower + upper);          // qsort.go:73-81
     if (n == 0) res = p.ref_loc;
-    if (on && role == 0) p.out[item] = res;
+    if (on && role == 0) NL_STORE_RESULT(&p.out[item], res);
 }
 
 hipError_t launch_stack_median_ml(const StackArgs &args, hipStream_t stream, const char **name)
@@ -545,7 +545,7 @@ void stack_mad_ml_kernel(StackArgs p, FastArgs q)
     if (n == 0) res = p.ref_loc;
     const bool rep = on && role == 0;
     const bool to_exact = rep && degenerate;
-    if (rep && !to_exact) p.out[pix] = res;
+    if (rep && !to_exact) NL_STORE_RESULT(&p.out[pix], res);
     if (!rep || to_exact || n == 0) { c_lo = 0; c_hi = 0; }
     const unsigned long long em = __ballot(to_exact);
     if (em) {

@@ -891,7 +891,7 @@ void stack_sigma_mlz_kernel(StackArgs p, FastArgs q)
     if (rec && on && role == 0) p.nrounds[pix] = (unsigned char)(to_generic ? 0 : min(rnd, kBoundRounds));
     const bool rep = on && role == 0 && !rec;
     if (rep && !to_generic && !to_exact) {
-        p.out[pix] = res;
+        NL_STORE_RESULT(&p.out[pix], res);
         c_lo_total += c_lo;
         c_hi_total += c_hi;
     }

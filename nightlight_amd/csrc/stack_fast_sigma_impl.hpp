@@ -622,7 +622,7 @@ void stack_sigma_fast_kernel(StackArgs p, FastArgs q)
         // what a lane that is through leaves behind: its result and counts, or its place on a hand-over / continuation list
         auto flush = [&]() NL_INL {
         if (on && !active && !to_generic && !to_exact && !defer) {
-            p.out[pix] = res;
+            NL_STORE_RESULT(&p.out[pix], res);
             c_lo_total += c_lo;
             c_hi_total += c_hi;
         }

@@ -6,6 +6,18 @@
 
 #include "../../include/nlstack.h"
 
+// Result stores of the streaming kernels are NONTEMPORAL (round 6): the one store per pixel a stack pass makes is
+// what the slow allocations of section 11.9 are slow beside -- reads + plain stores 6.12 against 6.77 TB/s, reads + nontemporal
+// stores 6.52 against 6.93 (tools/ubench/alloc_probe_modes.hip): +2.4 % on every frame buffer, +6.5 % on the unlucky ones.
+// NL_PLAIN_STORES (build switch) restores plain stores for A/B libraries.
+#if defined(__HIPCC__)
+#ifdef NL_PLAIN_STORES
+#define NL_STORE_RESULT(ptr, val) (*(ptr) = (val))
+#else
+#define NL_STORE_RESULT(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#endif
+#endif
+
 namespace nl {
 
 // 160 KiB LDS per CU (MI355X); a single workgroup may use all of it.

@@ -346,7 +346,7 @@ void stack_linfit_fast_kernel(StackArgs p, FastArgs q, LinfitStage g)
     // lanes that are still fitting after this stage's quota go to the next stage; the
     // rejections they made so far are final and are counted here
     const bool more = active;
-    if (on && !to_exact && !more) p.out[pix] = res;
+    if (on && !to_exact && !more) NL_STORE_RESULT(&p.out[pix], res);
     if (on && !to_exact) { c_lo += p_lo; c_hi += p_hi; }
     const unsigned long long mm = __ballot(more);
     if (mm) {

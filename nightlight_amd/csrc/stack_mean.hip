@@ -67,7 +67,11 @@ __global__ __launch_bounds__(256) void stack_mean_vec4_kernel(StackArgs p)
             const float den = W ? ws[j] : (float)c[j];
             rr[j] = (c[j] == 0) ? p.ref_loc : s[j] / den;
         }
-        reinterpret_cast<float4 *>(p.out)[q] = r;
+        {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 rv = {r.x, r.y, r.z, r.w};
+            NL_STORE_RESULT(reinterpret_cast<f4 *>(p.out) + q, rv);
+        }
     }
 }
 

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void stream128(const float *frames, float *out
     out[pix] = (s0 + s1) + (s2 + s3);
 }
 
-template <bool STORE>
+template <int STORE>
 __global__ __launch_bounds__(256) void vec4x8(const float *frames, float *out, long npix4, long stride)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void vec4x8(const float *frames, float *out, l
 #pragma unroll
         for (int j = 0; j < 8; j++) acc += v[j];
     }
-    if (STORE) reinterpret_cast<f4 *>(out)[i] = acc;
+    if (STORE == 2) __builtin_nontemporal_store(acc, reinterpret_cast<f4 *>(out) + i);
+    else if (STORE == 3) { if ((blockIdx.x & 7) == 0) reinterpret_cast<f4 *>(out)[i] = acc; }      // an eighth of the stores
+    else if (STORE == 1) reinterpret_cast<f4 *>(out)[i] = acc;
     else if (acc.x == 1.2345678e-30f && acc.y == 8.7654321e-31f) out[0] = acc.x;
 }
 
@@ -85,16 +87,16 @@ int main(int argc, char **argv)
         const float *f = buf[i];
         // first launch on untouched memory, single shot (what a create-time probe would see) and min of 3
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        hipEventRecord(e0); hipLaunchKernelGGL(vec4x8<false>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventRecord(e0); hipLaunchKernelGGL(vec4x8<0>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); hipEventRecord(e1); hipEventSynchronize(e1);
         float first = 0; hipEventElapsedTime(&first, e0, e1);
-        const float b = rate([&] { hipLaunchKernelGGL(vec4x8<false>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 0);
-        const float d0 = rate([&] { hipLaunchKernelGGL(vec4x8<true>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 4);
+        const float b = rate([&] { hipLaunchKernelGGL(vec4x8<0>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 0);
+        const float d0 = rate([&] { hipLaunchKernelGGL(vec4x8<1>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 4);
         printf("allocation %2d: D on the UNTOUCHED allocation %7.1f GB/s\n", i, d0);
         hipMemset(buf[i], 0, bytes);
         hipDeviceSynchronize();
         const float a = rate([&] { hipLaunchKernelGGL(stream128, dim3(g1), dim3(256), 0, 0, f, out, npix, stride); }, npix, 4);
-        const float c = rate([&] { hipLaunchKernelGGL(vec4x8<false>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 0);
-        const float d = rate([&] { hipLaunchKernelGGL(vec4x8<true>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 4);
+        const float c = rate([&] { hipLaunchKernelGGL(vec4x8<0>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 0);
+        const float d = rate([&] { hipLaunchKernelGGL(vec4x8<1>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 4);
         printf("allocation %2d at %p: A ref %7.1f | B untouched, no store %7.1f (first shot %.3f ms) | C touched, no store %7.1f | D touched, store %7.1f GB/s\n",
                i, (void *)buf[i], a, b, first, c, d);
         fflush(stdout);
@@ -109,13 +111,13 @@ int main(int argc, char **argv)
         printf("frames %2d: D with out buffers", i);
         for (int j = 0; j < 6; j++) {
             float *o = outs[j];
-            printf(" %6.0f", rate([&] { hipLaunchKernelGGL(vec4x8<true>, dim3(g4), dim3(256), 0, 0, f, o, npix / 4, stride); }, npix, 4));
+            printf(" %6.0f", rate([&] { hipLaunchKernelGGL(vec4x8<1>, dim3(g4), dim3(256), 0, 0, f, o, npix / 4, stride); }, npix, 4));
         }
         printf(" | offsets into out buffer 0 (4K 64K 1M 8M 32M):");
         const size_t offs[5] = {4u << 10, 64u << 10, 1u << 20, 8u << 20, 32u << 20};
         for (int j = 0; j < 5; j++) {
             float *o = outs[0] + offs[j] / 4;
-            printf(" %6.0f", rate([&] { hipLaunchKernelGGL(vec4x8<true>, dim3(g4), dim3(256), 0, 0, f, o, npix / 4, stride); }, npix, 4));
+            printf(" %6.0f", rate([&] { hipLaunchKernelGGL(vec4x8<1>, dim3(g4), dim3(256), 0, 0, f, o, npix / 4, stride); }, npix, 4));
         }
         printf("\n");
         fflush(stdout);
@@ -126,9 +128,11 @@ int main(int argc, char **argv)
     }
     for (int i = 0; i < nalloc && i < 32; i++) {
         const float *f = buf[i];
-        const float d = rate([&] { hipLaunchKernelGGL(vec4x8<true>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 4);
+        const float d = rate([&] { hipLaunchKernelGGL(vec4x8<1>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 4);
         const float a = rate([&] { hipLaunchKernelGGL(stream128, dim3(g1), dim3(256), 0, 0, f, out, npix, stride); }, npix, 4);
-        printf("noise-filled %2d: D store %7.1f | A ref %7.1f GB/s\n", i, d, a);
+        const float dn = rate([&] { hipLaunchKernelGGL(vec4x8<2>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 4);
+        const float d8 = rate([&] { hipLaunchKernelGGL(vec4x8<3>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 0);
+        printf("noise-filled %2d: D store %7.1f | D nontemporal store %7.1f | D an eighth of the stores %7.1f | A ref %7.1f GB/s\n", i, d, dn, d8, a);
     }
     return 0;
 }

@@ -52,6 +52,27 @@ __global__ __launch_bounds__(256) void fill_noise(float *p, long n)
     }
 }
 
+template <int AUX>
+__global__ __launch_bounds__(256) void vec4x8_aux(const float *frames, float *out, long npix4, long stride)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix4) return;
+    const f4 *base = reinterpret_cast<const f4 *>(frames) + i;
+    const long stride4 = stride >> 2;
+    f4 acc = {0, 0, 0, 0};
+    for (int k = 0; k < 128; k += 8) {
+        f4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = __builtin_nontemporal_load(base + (long)(k + j) * stride4);
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc += v[j];
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(npix4 * 16), 0x00020000);
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    i4 bits = {__float_as_int(acc.x), __float_as_int(acc.y), __float_as_int(acc.z), __float_as_int(acc.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(bits, rs, (int)(i * 16), 0, AUX);
+}
+
 template <class F>
 static float rate(F launch, long npix, int bytes_per_px_out)
 {
@@ -133,6 +154,10 @@ int main(int argc, char **argv)
         const float dn = rate([&] { hipLaunchKernelGGL(vec4x8<2>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 4);
         const float d8 = rate([&] { hipLaunchKernelGGL(vec4x8<3>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 0);
         printf("noise-filled %2d: D store %7.1f | D nontemporal store %7.1f | D an eighth of the stores %7.1f | A ref %7.1f GB/s\n", i, d, dn, d8, a);
+        printf("             buffer store aux 0 / 1 / 2 / 3 / 16 / 17 / 18 / 19:");
+#define AUXRUN(A) printf(" %6.0f", rate([&] { hipLaunchKernelGGL(vec4x8_aux<A>, dim3(g4), dim3(256), 0, 0, f, out, npix / 4, stride); }, npix, 4));
+        AUXRUN(0) AUXRUN(1) AUXRUN(2) AUXRUN(3) AUXRUN(16) AUXRUN(17) AUXRUN(18) AUXRUN(19)
+        printf("\n");
     }
     return 0;
 }

@@ -2312,7 +2312,7 @@ int nl_stack_upload_frame_fits_async(nl_stack_t *h, int idx, const void *raw_hos
     // The decode kernel reads the payload straight out of the pinned staging buffer (round 6): DMA into a device scratch
     // and a kernel behind it on one stream took turns -- copy engine, compute queue, copy engine ... with a dependency
     // hand-over each way -- and ran at 0.9 ms per 32 MiB int16 frame where the link needs 0.6 (bench.py apply_from_host:
-    // 34.7 GiB/s).  One kernel per frame that pulls its bytes over the link in 16-byte loads has no hand-over at all.
+    // 34.7 GiB/s).  One kernel per frame that pulls its bytes over the link itself (8- or 16-byte loads per lane) has no hand-over at all.
     // NL_FITS_ZEROCOPY=0: the DMA + kernel pair, for A/B runs.
     static const bool zero_copy = [] { const char *e = getenv("NL_FITS_ZEROCOPY"); return !e || atoi(e) != 0; }();
     const void *raw_dev = staged;
